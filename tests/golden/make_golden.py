@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference package from /root/reference (with the import-only
+`numba` stand-in in tests/golden/_numba_standin, because numba is not
+installable here), executes the reference's own functions on seeded inputs and
+stores inputs + outputs as small .npz files.  Nothing of the reference's source
+is stored; the fixtures are data.
+
+What each file pins (reference file:line):
+  psi_gammaln.npz      hpf_numba.psi / cgammaln (hpf_numba.py:16-22) == SciPy's
+                       C psi / gammaln, on the reference's own test points
+                       (tests/test_inference.py:24-37) plus a dense grid
+  ops_f64/f32.npz      compute_Xphi_data (:54-114), compute_Xphi_data_numpy
+                       (:117-125), compute_loading_shape_update (:128-156),
+                       compute_loading_rate_update (:159-177),
+                       compute_capacity_rate_update (:180-188), compute_pois_llh
+                       (:24-51) + the numpy llh (loss.py:132-134), on the
+                       reference's conftest recipe (tests/conftest.py:10-38)
+  fit_*.npz            whole scHPF.fit()/project() traces (scHPF_.py:425-503,
+                       526-780): bp, dp, per-check loss, final xi/theta/eta/beta
+  pbmc_like_data.npz   the COO the reference's loader makes of its own test data
+                       file tests/_data/PJ030merge...matrix.txt (data only)
+  ref_model_f64.joblib a model file written by the reference's save_model
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "_numba_standin"))
+
+import numpy as np  # noqa: E402
+from scipy.sparse import coo_matrix  # noqa: E402
+
+import schpf  # noqa: E402  (the reference)
+from schpf import hpf_numba, scHPF  # noqa: E402
+from schpf import preprocessing as prep  # noqa: E402
+import schpf.loss as ls  # noqa: E402
+
+assert schpf.__file__.startswith("/root/reference"), schpf.__file__
+
+
+def conftest_data(seed=42, ncells=300, ngenes=1000, frac=0.03):
+    """tests/conftest.py:14-25 recipe (module seed at :8)."""
+    np.random.seed(seed)
+    nnz = int(ncells * ngenes * frac)
+    x = np.random.negative_binomial(2, 0.5, nnz)
+    x[x == 0] = 1
+    ci = np.random.randint(0, ncells, nnz, dtype=np.int32)
+    gi = np.random.randint(0, ngenes, nnz, dtype=np.int32)
+    X = coo_matrix((x, (ci, gi)), (ncells, ngenes), dtype=np.int32)
+    X.sum_duplicates()
+    return X
+
+
+def gam(g):
+    return g.vi_shape.copy(), g.vi_rate.copy()
+
+
+def make_psi_gammaln():
+    pts = np.array([0.0001, 0.001, 0.01, 0.1, 1, 10, 100, 1000], dtype=np.float64)
+    grid = np.concatenate([
+        pts,
+        np.logspace(-4, 6, 1500),
+        np.linspace(0.9, 2.1, 241),          # around the positive root 1.4616
+        np.arange(1, 200, dtype=np.float64),  # integer counts + 1 for gammaln
+    ])
+    psi = np.array([hpf_numba.psi(float(v)) for v in grid])
+    gln = np.array([hpf_numba.cgammaln(float(v)) for v in grid])
+    np.savez_compressed(os.path.join(HERE, "psi_gammaln.npz"), x=grid, psi=psi,
+                        gammaln=gln, n_test_points=len(pts))
+
+
+def make_ops(dtype, tag):
+    X = conftest_data()
+    np.random.seed(1234)
+    model = scHPF(4, dtype=dtype)
+    model._initialize(X)
+    # Xphi fixture as tests/test_inference.py:17-20
+    random_phi = np.random.dirichlet(np.ones(model.nfactors), X.data.shape[0]).astype(dtype)
+    xphi_in = X.data[:, None] * random_phi
+    th, be, xi, eta = model.theta, model.beta, model.xi, model.eta
+    out = dict(
+        x=X.data, row=X.row, col=X.col, shape=np.array(X.shape),
+        theta_shape=th.vi_shape, theta_rate=th.vi_rate,
+        beta_shape=be.vi_shape, beta_rate=be.vi_rate,
+        xi_shape=xi.vi_shape, xi_rate=xi.vi_rate,
+        eta_shape=eta.vi_shape, eta_rate=eta.vi_rate,
+        a=model.a, c=model.c, ap=model.ap, cp=model.cp, bp=model.bp, dp=model.dp,
+        xphi_in=xphi_in,
+    )
+    out["xphi"] = hpf_numba.compute_Xphi_data(
+        X.data, X.row, X.col, th.vi_shape, th.vi_rate, be.vi_shape, be.vi_rate)
+    out["xphi_numpy"] = hpf_numba.compute_Xphi_data_numpy(X, th, be)
+    out["theta_shape_upd"] = hpf_numba.compute_loading_shape_update(
+        xphi_in, X.row, X.shape[0], model.a)
+    out["beta_shape_upd"] = hpf_numba.compute_loading_shape_update(
+        xphi_in, X.col, X.shape[1], model.c)
+    out["theta_rate_upd"] = hpf_numba.compute_loading_rate_update(
+        xi.vi_shape, xi.vi_rate, be.vi_shape, be.vi_rate)
+    out["beta_rate_upd"] = hpf_numba.compute_loading_rate_update(
+        eta.vi_shape, eta.vi_rate, th.vi_shape, th.vi_rate)
+    out["eta_rate_upd"] = hpf_numba.compute_capacity_rate_update(
+        be.vi_shape, be.vi_rate, model.dp)
+    out["xi_rate_upd"] = hpf_numba.compute_capacity_rate_update(
+        th.vi_shape, th.vi_rate, model.bp)
+    out["llh"] = hpf_numba.compute_pois_llh(
+        X.data, X.row, X.col, th.vi_shape, th.vi_rate, be.vi_shape, be.vi_rate)
+    out["llh_numpy"] = ls.pois_llh_pointwise(X, theta=th, beta=be, single_process=True)
+    out["mean_neg_llh"] = ls.mean_negative_pois_llh(X, theta=th, beta=be)
+    out["cell_score"] = model.cell_score()
+    out["gene_score"] = model.gene_score()
+    out["cellmean_neg_llh"] = model.cellmean_negative_pois_llh(X)
+    np.savez_compressed(os.path.join(HERE, "ops_%s.npz" % tag), **out)
+
+
+def trace(model, X, losses, extra=None):
+    d = dict(x=X.data, row=X.row, col=X.col, shape=np.array(X.shape),
+             bp=model.bp, dp=model.dp, loss=np.array(losses, dtype=np.float64),
+             nfactors=model.nfactors)
+    for name in ("xi", "theta", "eta", "beta"):
+        s, r = gam(getattr(model, name))
+        d[name + "_shape"], d[name + "_rate"] = s, r
+    if extra:
+        d.update(extra)
+    return d
+
+
+def make_fit(X, K, seed, dtype, fname, max_iter=60, **fit_kw):
+    np.random.seed(seed)
+    model = scHPF(K, dtype=dtype, max_iter=max_iter, verbose=False)
+    model.fit(X, **fit_kw)
+    d = trace(model, X, model.loss, dict(seed=seed, max_iter=max_iter, niter_checks=len(model.loss)))
+    np.savez_compressed(os.path.join(HERE, fname), **d)
+    return model
+
+
+def make_project(model, X, fname, seed=7):
+    """project() on the first 40 cells (scHPF_.py:448-503), reinit default."""
+    Xp = X.tocsr()[:40].tocoo()
+    np.random.seed(seed)
+    proj = model.project(Xp, max_iter=20)
+    d = trace(proj, Xp, proj.loss, dict(seed=seed))
+    np.savez_compressed(os.path.join(HERE, fname), **d)
+
+
+def main():
+    make_psi_gammaln()
+    make_ops(np.float64, "f64")
+    make_ops(np.float32, "f32")
+
+    txt = "/root/reference/tests/_data/PJ030merge.c300t400_g0t500.matrix.txt"
+    Xd, _genes = prep.load_txt(txt, verbose=False)
+    np.savez_compressed(os.path.join(HERE, "pbmc_like_data.npz"), x=Xd.data, row=Xd.row,
+                        col=Xd.col, shape=np.array(Xd.shape))
+    Xc = conftest_data()
+
+    m64 = make_fit(Xd, 5, 0, np.float64, "fit_data_k5_s0_f64.npz")
+    make_fit(Xd, 5, 1, np.float64, "fit_data_k5_s1_f64.npz")
+    make_fit(Xd, 5, 0, np.float32, "fit_data_k5_s0_f32.npz")
+    make_fit(Xc, 4, 0, np.float64, "fit_conf_k4_s0_f64.npz", max_iter=40)
+    make_fit(Xc, 4, 0, np.float32, "fit_conf_k4_s0_f32.npz", max_iter=40)
+    make_fit(Xd, 5, 0, np.float64, "fit_data_k5_s0_f64_simul.npz", max_iter=30,
+             beta_theta_simultaneous=True)
+    make_fit(Xd, 5, 0, np.float64, "fit_data_k5_s0_f64_single.npz", max_iter=30,
+             single_process=True)
+    make_fit(Xd, 5, 3, np.float64, "fit_data_k5_s3_f64_batch.npz", max_iter=30,
+             batchsize=32)
+    make_project(m64, Xd, "project_data_k5_f64.npz")
+    schpf.save_model(m64, os.path.join(HERE, "ref_model_f64.joblib"))
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
