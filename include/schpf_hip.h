@@ -1,0 +1,174 @@
+/*
+ * schpf_hip.h -- C ABI of libschpf_hip.so, the MI355X (gfx950) engine for the scHPF CAVI
+ * hot path.
+ *
+ * The reference (simslab/scHPF 0.5.0) has no FFI: its seam for this path is the set of
+ * numba-compiled Python callables in schpf/hpf_numba.py, imported by schpf/scHPF_.py:21
+ * and schpf/loss.py:13 and called only from scHPF._fit (scHPF_.py:642-715) and
+ * loss.pois_llh_pointwise (loss.py:136-138).  Every entry point below names the
+ * reference interface it replaces.  The binding a maintainer would add on the
+ * reference side is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; all array arguments of the stateless functions and of
+ *     set/get_state are HOST pointers to C-contiguous row-major buffers owned by the
+ *     caller for the duration of the call (nothing is retained);
+ *   - `dtype` selects the model precision T: SCHPF_F32 or SCHPF_F64 (the reference's
+ *     scHPF(dtype=...) / hpf_numba.py:30,80);  indices are int32 (SciPy COO default);
+ *   - every function returns 0 on success, non-zero on failure; schpf_last_error()
+ *     returns a message for the calling thread.  The library never aborts the process;
+ *   - one context = one GPU = one host thread at a time.  Work is enqueued on the
+ *     context's HIP stream; calls that return data to the host synchronise it.
+ */
+#ifndef SCHPF_HIP_H
+#define SCHPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCHPF_F32 0
+#define SCHPF_F64 1
+
+/* which variational distribution (scHPF_.py:264-267) */
+#define SCHPF_XI 0
+#define SCHPF_THETA 1
+#define SCHPF_ETA 2
+#define SCHPF_BETA 3
+
+/* element type of the COO values handed to schpf_upload_coo */
+#define SCHPF_VAL_I32 0
+#define SCHPF_VAL_I64 1
+#define SCHPF_VAL_F32 2
+#define SCHPF_VAL_F64 3
+
+/* step flags (keyword arguments of scHPF._fit, scHPF_.py:526-530) */
+#define SCHPF_FREEZE_GENES 1u   /* freeze_genes=True: skip the eta/beta block (project()) */
+#define SCHPF_SIMULTANEOUS 2u   /* beta_theta_simultaneous=True (scHPF_.py:666-685)      */
+#define SCHPF_SHARDED 4u        /* cells are sharded over several GPUs: gene-side sums go
+                                   through the exchange buffer (all-reduced by the host) */
+
+typedef struct schpf_ctx schpf_ctx;
+
+const char *schpf_last_error(void);
+int schpf_device_count(int *count);
+const char *schpf_version(void);
+
+/* ---------------------------------------------------------------------------------
+ * Stateless operator mirrors: array in, array out, caller's COO order.
+ * ------------------------------------------------------------------------------- */
+
+/* hpf_numba.psi / hpf_numba.cgammaln (hpf_numba.py:16-22): double -> double. */
+int schpf_digamma(int64_t n, const double *x, double *out);
+int schpf_gammaln(int64_t n, const double *x, double *out);
+
+/* compute_Xphi_data(X_data, X_row, X_col, theta_vi_shape, theta_vi_rate, beta_vi_shape,
+ * beta_vi_rate) -> Xphi (nnz, K)                              hpf_numba.py:54-114.
+ * x: (nnz,) of T;  row/col: (nnz,) int32;  theta_*: (ncells, K);  beta_*: (ngenes, K). */
+int schpf_xphi(int dtype, int64_t nnz, int ncells, int ngenes, int nfactors, const void *x,
+               const int32_t *row, const int32_t *col, const void *theta_shape,
+               const void *theta_rate, const void *beta_shape, const void *beta_rate, void *out);
+
+/* compute_pois_llh(...) -> llh (nnz,)                         hpf_numba.py:24-51. */
+int schpf_pois_llh_pointwise(int dtype, int64_t nnz, int ncells, int ngenes, int nfactors,
+                             const void *x, const int32_t *row, const int32_t *col,
+                             const void *theta_shape, const void *theta_rate,
+                             const void *beta_shape, const void *beta_rate, void *out);
+
+/* compute_loading_shape_update(Xphi_data, X_keep, nkeep, shape_prior) -> (nkeep, K)
+ *                                                             hpf_numba.py:128-156. */
+int schpf_shape_update(int dtype, int64_t nnz, int nfactors, const void *xphi,
+                       const int32_t *keep, int nkeep, double shape_prior, void *out);
+
+/* compute_loading_rate_update(prior_vi_shape, prior_vi_rate, other_loading_vi_shape,
+ * other_loading_vi_rate) -> (n, K)                            hpf_numba.py:159-177.
+ * prior_*: (n,);  other_*: (m, K). */
+int schpf_rate_update(int dtype, int n, int m, int nfactors, const void *prior_shape,
+                      const void *prior_rate, const void *other_shape, const void *other_rate,
+                      void *out);
+
+/* compute_capacity_rate_update(loading_vi_shape, loading_vi_rate, prior_rate) -> (n,)
+ *                                                             hpf_numba.py:180-188. */
+int schpf_capacity_rate_update(int dtype, int n, int nfactors, const void *shape,
+                               const void *rate, double prior_rate, void *out);
+
+/* ---------------------------------------------------------------------------------
+ * The engine: device-resident state for scHPF._fit's loop (scHPF_.py:642-715).
+ * ------------------------------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  `stream` is a hipStream_t to enqueue on
+ * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create one.
+ * ncells is the number of LOCAL cells when cells are sharded. */
+int schpf_create(schpf_ctx **out, int device, void *stream, int dtype, int ncells, int ngenes,
+                 int nfactors);
+int schpf_destroy(schpf_ctx *ctx);
+
+/* The count matrix X (scipy coo_matrix: X.row, X.col, X.data), any order, duplicates kept
+ * as separate observations like the reference (hpf_numba.py:98-112).  Builds both sweep
+ * plans and uploads them.  Values must be > 0 and exactly representable in float32. */
+int schpf_upload_coo(schpf_ctx *ctx, int64_t nnz, const int32_t *row, const int32_t *col,
+                     const void *val, int val_kind);
+
+/* a, c (shape priors of theta, beta) and bp, dp (rate hyper-priors; scHPF_.py:847-879).
+ * ap/cp only enter through the constant xi/eta shapes (scHPF_.py:616-618), which the
+ * caller sets with schpf_set_state. */
+int schpf_set_hypers(schpf_ctx *ctx, double a, double c, double bp, double dp);
+
+/* vi_shape / vi_rate of one HPF_Gamma (scHPF_.py:27-81); (n,) for xi/eta, (n, K) else. */
+int schpf_set_state(schpf_ctx *ctx, int which, const void *shape, const void *rate);
+int schpf_get_state(schpf_ctx *ctx, int which, void *shape, void *rate);
+
+/* t == 0 of a fit with reinit=True (scHPF_.py:652-655): X*phi with phi ~ Dirichlet(1_K).
+ * _host: the caller drew it (NumPy, seed-compatible with the reference) and passes
+ *        Xphi_data, (nnz, K) float64, in the order of the uploaded COO.
+ * _device: counter-based generator on the GPU (not NumPy-compatible; for matrices whose
+ *        nnz*K host draw is impractical).
+ * The next schpf_step / schpf_step_local consumes it instead of computing responsibilities. */
+int schpf_init_phi_host(schpf_ctx *ctx, const double *xphi);
+int schpf_init_phi_device(schpf_ctx *ctx, uint64_t seed);
+
+/* One CAVI iteration, the body of the loop at scHPF_.py:657-714 (non-batched order):
+ * responsibilities -> [beta.shape, beta.rate, eta.rate] -> [theta.shape, theta.rate,
+ * xi.rate].  schpf_step = schpf_step_local + schpf_step_finish on one GPU. */
+int schpf_step(schpf_ctx *ctx, unsigned flags);
+
+/* Sharded form: _local runs both sweeps and packs the gene-side sums [G*K] followed by
+ * the local sum_i E[theta_ik] [K] into the exchange buffer (device memory, dtype T);
+ * the host all-reduces (sum) that buffer over the ranks (RCCL), then calls _finish. */
+int schpf_step_local(schpf_ctx *ctx, unsigned flags);
+int schpf_exchange_buffer(schpf_ctx *ctx, void **device_ptr, int64_t *count);
+int schpf_step_finish(schpf_ctx *ctx, unsigned flags);
+
+/* Loss terms of mean_negative_pois_llh (loss.py:142-168) for the CURRENT state over the
+ * local nonzeros:  llh_sum = sum x*log(r) - r,  gammaln_sum = sum lgamma(x+1).
+ * mean negative llh = -(llh_sum - gammaln_sum) / nnz  (sum the three over ranks first). */
+int schpf_loss_terms(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64_t *nnz);
+
+int schpf_synchronize(schpf_ctx *ctx);
+
+/* HIP-event timing of the sweep kernel launches on the context's stream (bench.py).
+ * ms[0] = cell sweep, ms[1] = gene sweep, ms[2] = loss sweep, ms[3] = gamma updates;
+ * launches[] likewise.  Reading synchronises the stream and resets the counters. */
+int schpf_profile_enable(schpf_ctx *ctx, int enable);
+int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
+
+/* Plan facts for reports: info[0..] = KP, KL, LPC, chunk_len, windows_cell, windows_gene,
+ * n_chunks_cell, n_chunks_gene, n_waves_cell, n_waves_gene, stored entry slots cell, gene */
+int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]);
+
+/* Test hook (host only, no GPU needed): build one sweep plan from (major, minor, val) and expand
+ * it back into per-nonzero records in storage order -- the major/minor/val it will be processed
+ * with, the partials row (natural chunk id) it accumulates into and the wavefront that streams
+ * it -- plus cptr[n_major + 1] and stats = {n_chunks, n_slices, n_waves, stored entry slots}. */
+int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                            int n_major, int n_minor, int lpc, int chunk_len, int n_windows,
+                            int32_t *out_major, int32_t *out_minor, float *out_val,
+                            int32_t *out_natid, int32_t *out_wave, int32_t *out_cptr,
+                            int64_t stats[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCHPF_HIP_H */

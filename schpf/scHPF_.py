@@ -1,0 +1,3 @@
+"""Alias of schpf_amd.scHPF_ under the reference's module path (pickle compatibility)."""
+from schpf_amd.scHPF_ import *  # noqa: F401,F403
+from schpf_amd.scHPF_ import HPF_Gamma, scHPF, load_model, save_model, combine_across_cells  # noqa: F401

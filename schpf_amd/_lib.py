@@ -1,0 +1,112 @@
+"""ctypes binding of libschpf_hip.so (the C ABI declared in include/schpf_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded the
+import of anything that computes raises, loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libschpf_hip.so")
+
+F32, F64 = 0, 1
+XI, THETA, ETA, BETA = 0, 1, 2, 3
+VAL_I32, VAL_I64, VAL_F32, VAL_F64 = 0, 1, 2, 3
+FREEZE_GENES, SIMULTANEOUS, SHARDED = 1, 2, 4
+
+_vp = ctypes.c_void_p
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+_dblp = ctypes.POINTER(ctypes.c_double)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+# name -> argtypes; every function returns int status (0 = ok)
+SIGNATURES = {
+    "schpf_device_count": [ctypes.POINTER(_int)],
+    "schpf_digamma": [_i64, _vp, _vp],
+    "schpf_gammaln": [_i64, _vp, _vp],
+    "schpf_xphi": [_int, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "schpf_pois_llh_pointwise": [_int, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "schpf_shape_update": [_int, _i64, _int, _vp, _vp, _int, _dbl, _vp],
+    "schpf_rate_update": [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp],
+    "schpf_capacity_rate_update": [_int, _int, _int, _vp, _vp, _dbl, _vp],
+    "schpf_create": [ctypes.POINTER(_vp), _int, _vp, _int, _int, _int, _int],
+    "schpf_destroy": [_vp],
+    "schpf_upload_coo": [_vp, _i64, _vp, _vp, _vp, _int],
+    "schpf_set_hypers": [_vp, _dbl, _dbl, _dbl, _dbl],
+    "schpf_set_state": [_vp, _int, _vp, _vp],
+    "schpf_get_state": [_vp, _int, _vp, _vp],
+    "schpf_init_phi_host": [_vp, _vp],
+    "schpf_init_phi_device": [_vp, ctypes.c_uint64],
+    "schpf_step": [_vp, ctypes.c_uint],
+    "schpf_step_local": [_vp, ctypes.c_uint],
+    "schpf_exchange_buffer": [_vp, ctypes.POINTER(_vp), _i64p],
+    "schpf_step_finish": [_vp, ctypes.c_uint],
+    "schpf_loss_terms": [_vp, _dblp, _dblp, _i64p],
+    "schpf_synchronize": [_vp],
+    "schpf_profile_enable": [_vp, _int],
+    "schpf_profile_read": [_vp, _dblp, _i64p],
+    "schpf_plan_info": [_vp, _i64p],
+    "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _i64p],
+}
+STRING_FUNCS = ("schpf_last_error", "schpf_version")
+
+_lib = None
+
+
+class SchpfHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libschpf_hip.so for gfx950 with hipcc (schpf_amd/csrc/Makefile)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-s", "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SchpfHipError(
+            "libschpf_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    for name in STRING_FUNCS:
+        getattr(lib, name).restype = ctypes.c_char_p
+        getattr(lib, name).argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().schpf_last_error().decode("utf-8", "replace")
+        if "must be" in msg or "out of range" in msg or "unknown" in msg:
+            raise ValueError(msg)
+        raise SchpfHipError(msg)
+
+
+def device_count():
+    n = _int(0)
+    check(load().schpf_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise SchpfHipError("no HIP device visible: schpf_amd computes only on an AMD GPU "
+                            "(MI355X / gfx950); there is no CPU fallback")

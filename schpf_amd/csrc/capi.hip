@@ -1,0 +1,898 @@
+// C ABI of libschpf_hip.so (include/schpf_hip.h): context management, uploads, and the
+// ordering of kernel launches that makes one CAVI iteration (scHPF_.py:657-714).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/schpf_hip.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            char b_[512];                                                                    \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                     __FILE__, __LINE__);                                                    \
+            throw HipError(b_);                                                              \
+        }                                                                                    \
+    } while (0)
+
+template <typename F> int guarded(F &&f)
+{
+    try {
+        f();
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 1;
+    } catch (...) {
+        g_err = "unknown error";
+        return 1;
+    }
+}
+
+// RAII device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    void alloc(size_t n, bool zero = false, hipStream_t st = nullptr)
+    {
+        release();
+        bytes = n ? n : 16;
+        HIPCHK(hipMalloc(&p, bytes));
+        if (zero) HIPCHK(hipMemsetAsync(p, 0, bytes, st));
+    }
+    template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
+};
+
+template <typename U> void upload(DevBuf &b, const std::vector<U> &v, hipStream_t st)
+{
+    b.alloc(v.size() * sizeof(U));
+    if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice, st));
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+struct PlanDev {
+    schpf::SweepPlanHost host;  // entries cleared after upload; order/mptr/cptr kept
+    DevBuf entries, slice_off, slice_steps, chunk_major, chunk_natid, wave_slice, cptr, partials;
+    int64_t n_waves = 0, n_chunks = 0, entry_slots = 0;
+};
+
+struct Profiler {
+    bool on = false;
+    struct Rec { int kind; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    ~Profiler()
+    {
+        for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+struct ScopedTimer {
+    Profiler &p; hipStream_t st; int kind; hipEvent_t a{}, b{};
+    ScopedTimer(Profiler &p_, hipStream_t st_, int kind_) : p(p_), st(st_), kind(kind_)
+    {
+        if (p.on) { a = p.get(); b = p.get(); HIPCHK(hipEventRecord(a, st)); }
+    }
+    void stop()
+    {
+        if (p.on) { HIPCHK(hipEventRecord(b, st)); p.recs.push_back({kind, a, b}); }
+    }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+struct schpf_ctx {
+    int device = 0, dtype = SCHPF_F64, N = 0, G = 0, K = 0;
+    int KP = 0, KL = 0, LPC = 1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    virtual ~schpf_ctx() {}
+    virtual void upload_coo(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind) = 0;
+    virtual void set_state(int which, const void *shape, const void *rate) = 0;
+    virtual void get_state(int which, void *shape, void *rate) = 0;
+    virtual void init_phi_host(const double *xphi) = 0;
+    virtual void init_phi_device(uint64_t seed) = 0;
+    virtual void step_local(unsigned flags) = 0;
+    virtual void step_finish(unsigned flags) = 0;
+    virtual void exchange(void **p, int64_t *count) = 0;
+    virtual void loss_terms(double *llh, double *gl, int64_t *nnz) = 0;
+    virtual void plan_info(int64_t info[12]) = 0;
+    double a = 0.3, c = 0.3, bp = 1.0, dp = 1.0;
+    Profiler prof;
+};
+
+namespace {
+
+template <typename T> struct Engine final : schpf_ctx {
+    // variational parameters (C-contiguous, stride K)
+    DevBuf xi_s, xi_r, th_s, th_r, eta_s, eta_r, be_s, be_r;
+    // tables, stride KP, padding columns zero
+    DevBuf th_exp, th_e, th_log, be_exp, be_e, be_log;
+    DevBuf extra_cell, extra_gene, flags;           // fallback accumulators + 2 int flags
+    DevBuf exchange_buf;                            // [G*K + K] of T
+    DevBuf dense_cell;                              // [N*K] of T (t = 0 only)
+    DevBuf s_theta, s_beta, s_beta_next;            // double[K]
+    DevBuf colpart_cell, colpart_gene;              // double[UPD_BLOCKS * K]
+    DevBuf wave_out, scalars;                       // llh per wave; scalars[0]=llh sum
+    PlanDev cell, gene;                             // major = cell / major = gene
+    int64_t nnz = 0;
+    double gammaln_sum = 0.0;
+    bool have_coo = false;
+    bool dirty_theta = true, dirty_beta = true;
+    int pending_init = 0;  // 0 none, 1 dense accumulators, 2 chunk partials
+    static constexpr int UPD_BLOCKS = 1024;
+
+    Engine(int device_, void *stream_, int dtype_, int N_, int G_, int K_)
+    {
+        device = device_; dtype = dtype_; N = N_; G = G_; K = K_;
+        HIPCHK(hipSetDevice(device));
+        if (stream_) stream = (hipStream_t)stream_;
+        else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+        choose_config();
+        const size_t s = sizeof(T);
+        xi_s.alloc((size_t)N * s); xi_r.alloc((size_t)N * s);
+        eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
+        th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
+        be_s.alloc((size_t)G * K * s); be_r.alloc((size_t)G * K * s);
+        for (DevBuf *b : {&th_exp, &th_e, &th_log, &extra_cell}) b->alloc((size_t)N * KP * s, true, stream);
+        for (DevBuf *b : {&be_exp, &be_e, &be_log, &extra_gene}) b->alloc((size_t)G * KP * s, true, stream);
+        flags.alloc(2 * sizeof(int), true, stream);
+        exchange_buf.alloc(((size_t)G * K + K) * s, true, stream);
+        for (DevBuf *b : {&s_theta, &s_beta, &s_beta_next}) b->alloc((size_t)K * sizeof(double), true, stream);
+        colpart_cell.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
+        colpart_gene.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
+        scalars.alloc(8 * sizeof(double), true, stream);
+    }
+    ~Engine() override
+    {
+        (void)hipStreamSynchronize(stream);
+        if (own_stream) (void)hipStreamDestroy(stream);
+    }
+
+    void choose_config()
+    {
+        if (K < 1 || K > 256) throw std::invalid_argument("nfactors must be in [1, 256]");
+        const bool f64 = sizeof(T) == 8;
+        int lpc = env_int("SCHPF_LPC", 0);
+        if (!lpc) {
+            const int per_lane = f64 ? 12 : 24;  // K values one lane keeps three copies of
+            lpc = 1;
+            while (lpc < 8 && (K + lpc - 1) / lpc > per_lane) lpc *= 2;
+        }
+        if (lpc != 1 && lpc != 2 && lpc != 4 && lpc != 8) throw std::invalid_argument("SCHPF_LPC must be 1,2,4,8");
+        const int need = (K + lpc - 1) / lpc;
+        static const int kl_f32[] = {4, 8, 12, 16, 20, 24, 32};
+        static const int kl_f64[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
+        int kl = 0;
+        if (f64) { for (int v : kl_f64) if (v >= need) { kl = v; break; } }
+        else { for (int v : kl_f32) if (v >= need) { kl = v; break; } }
+        if (!kl) throw std::invalid_argument("nfactors too large for this lanes-per-chunk setting");
+        LPC = lpc; KL = kl; KP = kl * lpc;
+    }
+
+    static int pick_windows(size_t table_bytes, const char *envname)
+    {
+        int w = env_int(envname, 0);
+        if (w > 0) return w;
+        const size_t budget = (size_t)env_int("SCHPF_L2_BUDGET_KB", 2048) * 1024;
+        w = 1;
+        while ((table_bytes + w - 1) / w > budget && w < 4096) w *= 2;
+        return w;
+    }
+
+    void build_plan(PlanDev &pd, int64_t nnz_, const int32_t *major, const int32_t *minor, const float *val,
+                    int n_major, int n_minor, int windows, int chunk_len)
+    {
+        schpf::build_sweep_plan(nnz_, major, minor, val, n_major, n_minor, LPC, chunk_len, windows, true,
+                                pd.host);
+        auto &h = pd.host;
+        pd.n_waves = h.n_waves;
+        pd.n_chunks = h.n_chunks;
+        pd.entry_slots = (int64_t)h.entries.size() / 2;
+        upload(pd.entries, h.entries, stream);
+        upload(pd.slice_off, h.slice_off, stream);
+        upload(pd.slice_steps, h.slice_steps, stream);
+        upload(pd.chunk_major, h.chunk_major, stream);
+        upload(pd.chunk_natid, h.chunk_natid, stream);
+        upload(pd.wave_slice, h.wave_slice, stream);
+        upload(pd.cptr, h.cptr, stream);
+        pd.partials.alloc((size_t)std::max<int64_t>(h.n_chunks, 1) * KP * sizeof(T), true, stream);
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<uint32_t>().swap(h.entries);
+        std::vector<int32_t>().swap(h.chunk_major);
+        std::vector<int32_t>().swap(h.chunk_natid);
+        std::vector<int32_t>().swap(h.wave_slice);
+        std::vector<int64_t>().swap(h.slice_off);
+        std::vector<int32_t>().swap(h.slice_steps);
+    }
+
+    void upload_coo(int64_t nnz_, const int32_t *row, const int32_t *col, const void *val, int kind) override
+    {
+        if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
+        std::vector<float> v((size_t)nnz_);
+        for (int64_t i = 0; i < nnz_; ++i) {
+            double d;
+            switch (kind) {
+            case SCHPF_VAL_I32: d = (double)((const int32_t *)val)[i]; break;
+            case SCHPF_VAL_I64: d = (double)((const int64_t *)val)[i]; break;
+            case SCHPF_VAL_F32: d = (double)((const float *)val)[i]; break;
+            case SCHPF_VAL_F64: d = ((const double *)val)[i]; break;
+            default: throw std::invalid_argument("unknown value kind");
+            }
+            const float f = (float)d;
+            if (!(d > 0.0) || (double)f != d)
+                throw std::invalid_argument("X.data must be > 0 and exactly representable in float32 "
+                                            "(UMI counts are); offending entry " + std::to_string(i));
+            if (row[i] < 0 || row[i] >= N || col[i] < 0 || col[i] >= G)
+                throw std::invalid_argument("COO index out of range at entry " + std::to_string(i));
+            v[(size_t)i] = f;
+        }
+        nnz = nnz_;
+        const int cpw = 64 / LPC;
+        int chunk = env_int("SCHPF_CHUNK", 0);
+        if (!chunk) {
+            const int64_t target_waves = 16384;
+            int64_t c = nnz / (target_waves * cpw);
+            chunk = 16;
+            while (chunk * 2 <= c && chunk < 256) chunk *= 2;
+        }
+        if (chunk < 2) chunk = 2;
+        chunk &= ~1;
+        const int wc = pick_windows((size_t)G * KP * sizeof(T), "SCHPF_WINDOWS_CELL");
+        const int wg = pick_windows((size_t)N * KP * sizeof(T), "SCHPF_WINDOWS_GENE");
+        build_plan(cell, nnz, row, col, v.data(), N, G, wc, chunk);
+        build_plan(gene, nnz, col, row, v.data(), G, N, wg, chunk);
+        wave_out.alloc((size_t)std::max<int64_t>(cell.n_waves, 1) * sizeof(double), true, stream);
+
+        // constant term of the loss: sum lgamma(x + 1)   (hpf_numba.py:49-50)
+        DevBuf dv, part;
+        upload(dv, v, stream);
+        const int nb = 512;
+        part.alloc(nb * sizeof(double));
+        HIPCHK(schpf::launch_gammaln_sum(dv.as<float>(), nnz, part.as<double>(), nb, stream));
+        HIPCHK(schpf::launch_sum_doubles(part.as<double>(), nb, scalars.as<double>() + 1, stream));
+        HIPCHK(hipMemcpyAsync(&gammaln_sum, scalars.as<double>() + 1, sizeof(double), hipMemcpyDeviceToHost,
+                              stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        have_coo = true;
+        pending_init = 0;
+    }
+
+    DevBuf &shape_buf(int which)
+    {
+        switch (which) {
+        case SCHPF_XI: return xi_s;
+        case SCHPF_THETA: return th_s;
+        case SCHPF_ETA: return eta_s;
+        case SCHPF_BETA: return be_s;
+        }
+        throw std::invalid_argument("which must be SCHPF_XI/THETA/ETA/BETA");
+    }
+    DevBuf &rate_buf(int which)
+    {
+        switch (which) {
+        case SCHPF_XI: return xi_r;
+        case SCHPF_THETA: return th_r;
+        case SCHPF_ETA: return eta_r;
+        case SCHPF_BETA: return be_r;
+        }
+        throw std::invalid_argument("which must be SCHPF_XI/THETA/ETA/BETA");
+    }
+    size_t state_bytes(int which) const
+    {
+        const size_t n = (which == SCHPF_XI || which == SCHPF_THETA) ? (size_t)N : (size_t)G;
+        const size_t k = (which == SCHPF_THETA || which == SCHPF_BETA) ? (size_t)K : 1;
+        return n * k * sizeof(T);
+    }
+    void set_state(int which, const void *shape, const void *rate) override
+    {
+        const size_t b = state_bytes(which);
+        if (shape) HIPCHK(hipMemcpyAsync(shape_buf(which).p, shape, b, hipMemcpyHostToDevice, stream));
+        if (rate) HIPCHK(hipMemcpyAsync(rate_buf(which).p, rate, b, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (which == SCHPF_THETA) dirty_theta = true;
+        if (which == SCHPF_BETA) dirty_beta = true;
+    }
+    void get_state(int which, void *shape, void *rate) override
+    {
+        const size_t b = state_bytes(which);
+        if (shape) HIPCHK(hipMemcpyAsync(shape, shape_buf(which).p, b, hipMemcpyDeviceToHost, stream));
+        if (rate) HIPCHK(hipMemcpyAsync(rate, rate_buf(which).p, b, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+
+    int rows_per_block() const { return 256 / K; }
+    int upd_blocks(int n) const
+    {
+        const int groups = (n + rows_per_block() - 1) / rows_per_block();
+        return std::max(1, std::min(groups, (int)UPD_BLOCKS));
+    }
+
+    // (re)build E, E[log], exp-shifted tables and column sums from the stored parameters
+    void refresh_tables()
+    {
+        if (dirty_theta) {
+            schpf::UpdateArgs<T> u{};
+            u.n = N; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
+            u.shape = th_s.as<T>(); u.rate = th_r.as<T>();
+            u.tab_e = th_e.as<T>(); u.tab_log = th_log.as<T>(); u.tab_exp = th_exp.as<T>();
+            u.colsum_part = colpart_cell.as<double>();
+            const int nb = upd_blocks(N);
+            HIPCHK(schpf::launch_gamma_update(u, schpf::SRC_NONE, nb, stream));
+            HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
+                                               exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
+            dirty_theta = false;
+        }
+        if (dirty_beta) {
+            schpf::UpdateArgs<T> u{};
+            u.n = G; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
+            u.shape = be_s.as<T>(); u.rate = be_r.as<T>();
+            u.tab_e = be_e.as<T>(); u.tab_log = be_log.as<T>(); u.tab_exp = be_exp.as<T>();
+            u.colsum_part = colpart_gene.as<double>();
+            const int nb = upd_blocks(G);
+            HIPCHK(schpf::launch_gamma_update(u, schpf::SRC_NONE, nb, stream));
+            HIPCHK(schpf::launch_colsum_reduce(colpart_gene.as<double>(), nb, K, s_beta.as<double>(), nullptr, 0,
+                                               stream));
+            dirty_beta = false;
+        }
+    }
+
+    schpf::SweepArgs<T> sweep_args(PlanDev &pd, const DevBuf &tab_major, const DevBuf &tab_minor,
+                                   const DevBuf &log_major, const DevBuf &log_minor, DevBuf &extra, int flag_ix)
+    {
+        schpf::SweepArgs<T> a{};
+        a.entries = pd.entries.as<uint4>();
+        a.slice_off = pd.slice_off.as<int64_t>();
+        a.slice_steps = pd.slice_steps.as<int>();
+        a.chunk_major = pd.chunk_major.as<int>();
+        a.chunk_natid = pd.chunk_natid.as<int>();
+        a.wave_slice = pd.wave_slice.as<int>();
+        a.tab_major = tab_major.as<T>();
+        a.tab_minor = tab_minor.as<T>();
+        a.log_major = log_major.as<T>();
+        a.log_minor = log_minor.as<T>();
+        a.partials = pd.partials.as<T>();
+        a.extra = extra.as<T>();
+        a.extra_flag = flags.as<int>() + flag_ix;
+        a.wave_out = wave_out.as<double>();
+        a.K = K;
+        return a;
+    }
+
+    void need_coo() const
+    {
+        if (!have_coo) throw std::logic_error("no count matrix uploaded (schpf_upload_coo)");
+    }
+
+    void init_phi_host(const double *xphi) override
+    {
+        need_coo();
+        DevBuf dx, ord, mp;
+        dx.alloc((size_t)nnz * K * sizeof(double));
+        HIPCHK(hipMemcpyAsync(dx.p, xphi, (size_t)nnz * K * sizeof(double), hipMemcpyHostToDevice, stream));
+        dense_cell.alloc((size_t)N * K * sizeof(T));
+        upload(ord, cell.host.order, stream);
+        upload(mp, cell.host.mptr, stream);
+        HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord.as<int>(), mp.as<int64_t>(), N, K,
+                                            dense_cell.as<T>(), stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        upload(ord, gene.host.order, stream);
+        upload(mp, gene.host.mptr, stream);
+        HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord.as<int>(), mp.as<int64_t>(), G, K,
+                                            exchange_buf.as<T>(), stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        pending_init = 1;
+    }
+
+    void init_phi_device(uint64_t seed) override
+    {
+        need_coo();
+        auto ac = sweep_args(cell, th_exp, be_exp, th_log, be_log, extra_cell, 0);
+        HIPCHK(schpf::launch_random_phi<T>(ac, KL, LPC, seed, 1, cell.n_waves, stream));
+        auto ag = sweep_args(gene, be_exp, th_exp, be_log, th_log, extra_gene, 1);
+        HIPCHK(schpf::launch_random_phi<T>(ag, KL, LPC, seed, 0, gene.n_waves, stream));
+        pending_init = 2;
+    }
+
+    void step_local(unsigned flags_) override
+    {
+        need_coo();
+        refresh_tables();
+        const bool freeze = flags_ & SCHPF_FREEZE_GENES;
+        const bool sharded = flags_ & SCHPF_SHARDED;
+        if (pending_init == 0) {
+            {
+                ScopedTimer tm(prof, stream, 0);
+                auto ac = sweep_args(cell, th_exp, be_exp, th_log, be_log, extra_cell, 0);
+                HIPCHK(schpf::launch_sweep<T>(ac, KL, LPC, schpf::MODE_PHI, cell.n_waves, stream));
+                tm.stop();
+            }
+            if (!freeze) {
+                ScopedTimer tm(prof, stream, 1);
+                auto ag = sweep_args(gene, be_exp, th_exp, be_log, th_log, extra_gene, 1);
+                HIPCHK(schpf::launch_sweep<T>(ag, KL, LPC, schpf::MODE_PHI, gene.n_waves, stream));
+                tm.stop();
+            }
+        }
+        if (sharded && !freeze && pending_init != 1) {
+            // fixed-order reduction of this rank's gene-side chunk partials into the exchange buffer
+            HIPCHK(schpf::launch_combine_partials<T>(gene.partials.as<T>(), gene.cptr.as<int>(), G, K, KP,
+                                                     extra_gene.as<T>(), flags.as<int>() + 1,
+                                                     exchange_buf.as<T>(), stream));
+        }
+    }
+
+    void exchange(void **p, int64_t *count) override
+    {
+        *p = exchange_buf.p;
+        *count = (int64_t)G * K + K;
+    }
+
+    void step_finish(unsigned flags_) override
+    {
+        need_coo();
+        const bool freeze = flags_ & SCHPF_FREEZE_GENES;
+        const bool simultaneous = flags_ & SCHPF_SIMULTANEOUS;
+        const bool sharded = flags_ & SCHPF_SHARDED;
+        ScopedTimer tm(prof, stream, 3);
+        // sharded: the all-reduced sum_i E[theta_ik] (old theta) is the tail of the exchange buffer
+        if (sharded) widen_tail();
+        if (!freeze) {  // gene block, scHPF_.py:697-704 (or :668-673 + :682-685)
+            schpf::UpdateArgs<T> u{};
+            u.n = G; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
+            int src;
+            if (sharded || pending_init == 1) { src = schpf::SRC_DENSE; u.dense = exchange_buf.as<T>(); }
+            else {
+                src = schpf::SRC_PARTIALS;
+                u.partials = gene.partials.as<T>(); u.cptr = gene.cptr.as<int>();
+                u.extra = extra_gene.as<T>(); u.extra_flag = flags.as<int>() + 1;
+            }
+            u.prior_shape = c;
+            u.cap_shape = eta_s.as<T>(); u.cap_rate = eta_r.as<T>();
+            u.s_other = s_theta.as<double>();
+            u.cap_prior_rate = dp;
+            u.shape = be_s.as<T>(); u.rate = be_r.as<T>(); u.cap_rate_out = eta_r.as<T>();
+            u.tab_e = be_e.as<T>(); u.tab_log = be_log.as<T>(); u.tab_exp = be_exp.as<T>();
+            u.colsum_part = colpart_gene.as<double>();
+            const int nb = upd_blocks(G);
+            HIPCHK(schpf::launch_gamma_update(u, src, nb, stream));
+            HIPCHK(schpf::launch_colsum_reduce(colpart_gene.as<double>(), nb, K, s_beta_next.as<double>(), nullptr,
+                                               0, stream));
+        }
+        {  // cell block, scHPF_.py:706-714 (or :675-680)
+            schpf::UpdateArgs<T> u{};
+            u.n = N; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
+            int src;
+            if (pending_init == 1) { src = schpf::SRC_DENSE; u.dense = dense_cell.as<T>(); }
+            else {
+                src = schpf::SRC_PARTIALS;
+                u.partials = cell.partials.as<T>(); u.cptr = cell.cptr.as<int>();
+                u.extra = extra_cell.as<T>(); u.extra_flag = flags.as<int>() + 0;
+            }
+            u.prior_shape = a;
+            u.cap_shape = xi_s.as<T>(); u.cap_rate = xi_r.as<T>();
+            // theta.rate uses the beta just updated (scHPF_.py:711-713) unless the updates are
+            // simultaneous (:677-679) or the genes are frozen
+            u.s_other = (freeze || simultaneous) ? s_beta.as<double>() : s_beta_next.as<double>();
+            u.cap_prior_rate = bp;
+            u.shape = th_s.as<T>(); u.rate = th_r.as<T>(); u.cap_rate_out = xi_r.as<T>();
+            u.tab_e = th_e.as<T>(); u.tab_log = th_log.as<T>(); u.tab_exp = th_exp.as<T>();
+            u.colsum_part = colpart_cell.as<double>();
+            const int nb = upd_blocks(N);
+            HIPCHK(schpf::launch_gamma_update(u, src, nb, stream));
+            HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
+                                               exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
+        }
+        if (!freeze) std::swap(s_beta.p, s_beta_next.p);
+        // both consumers of the fallback accumulators have run: clear their flags
+        HIPCHK(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), stream));
+        if (pending_init == 1) dense_cell.release();
+        pending_init = 0;
+        tm.stop();
+    }
+
+    void widen_tail();  // exchange tail (T) -> s_theta (double)
+
+    void loss_terms(double *llh, double *gl, int64_t *nnz_out) override
+    {
+        need_coo();
+        refresh_tables();
+        ScopedTimer tm(prof, stream, 2);
+        auto ac = sweep_args(cell, th_e, be_e, th_log, be_log, extra_cell, 0);
+        HIPCHK(schpf::launch_sweep<T>(ac, KL, LPC, schpf::MODE_LLH, cell.n_waves, stream));
+        HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(), cell.n_waves, scalars.as<double>(), stream));
+        tm.stop();
+        double h = 0.0;
+        HIPCHK(hipMemcpyAsync(&h, scalars.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        *llh = h;
+        *gl = gammaln_sum;
+        *nnz_out = nnz;
+    }
+
+    void plan_info(int64_t info[12]) override
+    {
+        info[0] = KP; info[1] = KL; info[2] = LPC;
+        info[3] = cell.host.chunk_len;
+        info[4] = cell.host.n_windows; info[5] = gene.host.n_windows;
+        info[6] = cell.n_chunks; info[7] = gene.n_chunks;
+        info[8] = cell.n_waves; info[9] = gene.n_waves;
+        info[10] = cell.entry_slots; info[11] = gene.entry_slots;
+    }
+};
+
+// tiny widening kernel for the sharded path: exchange tail (T) -> double[K]
+template <typename T> __global__ void widen_kernel(const T *__restrict__ in, int n, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+template <typename T> void Engine<T>::widen_tail()
+{
+    hipLaunchKernelGGL((widen_kernel<T>), dim3(1), dim3(256), 0, stream, exchange_buf.as<T>() + (size_t)G * K, K,
+                       s_theta.as<double>());
+    HIPCHK(hipGetLastError());
+}
+
+// ------------------------------------------------------------- stateless helpers
+struct TempStream {
+    hipStream_t st = nullptr;
+    TempStream() { HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); }
+    ~TempStream() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+};
+
+template <typename U> void h2d(DevBuf &b, const void *src, size_t count, hipStream_t st)
+{
+    b.alloc(count * sizeof(U));
+    if (count) HIPCHK(hipMemcpyAsync(b.p, src, count * sizeof(U), hipMemcpyHostToDevice, st));
+}
+void d2h(void *dst, const DevBuf &b, size_t bytes, hipStream_t st)
+{
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+}
+
+void check_indices(int64_t nnz, const int32_t *ix, int n, const char *what)
+{
+    for (int64_t i = 0; i < nnz; ++i)
+        if (ix[i] < 0 || ix[i] >= n) throw std::invalid_argument(std::string(what) + " index out of range");
+}
+
+template <typename T>
+void xphi_or_llh(bool want_llh, int64_t nnz, int N, int G, int K, const void *x, const int32_t *row,
+                 const int32_t *col, const void *ths, const void *thr, const void *bes, const void *ber, void *out)
+{
+    check_indices(nnz, row, N, "row");
+    check_indices(nnz, col, G, "col");
+    TempStream ts;
+    DevBuf dx, dr, dc, a, b, c, d, tt, tb, o;
+    h2d<T>(dx, x, (size_t)nnz, ts.st);
+    h2d<int32_t>(dr, row, (size_t)nnz, ts.st);
+    h2d<int32_t>(dc, col, (size_t)nnz, ts.st);
+    h2d<T>(a, ths, (size_t)N * K, ts.st); h2d<T>(b, thr, (size_t)N * K, ts.st);
+    h2d<T>(c, bes, (size_t)G * K, ts.st); h2d<T>(d, ber, (size_t)G * K, ts.st);
+    tt.alloc((size_t)N * K * sizeof(T)); tb.alloc((size_t)G * K * sizeof(T));
+    if (want_llh) {
+        HIPCHK(schpf::launch_ratio<T>(a.as<T>(), b.as<T>(), (int64_t)N * K, tt.as<T>(), ts.st));
+        HIPCHK(schpf::launch_ratio<T>(c.as<T>(), d.as<T>(), (int64_t)G * K, tb.as<T>(), ts.st));
+        o.alloc((size_t)nnz * sizeof(T));
+        HIPCHK(schpf::launch_llh_coo<T>(dx.as<T>(), dr.as<int>(), dc.as<int>(), tt.as<T>(), tb.as<T>(), nnz, K,
+                                        o.as<T>(), ts.st));
+        d2h(out, o, (size_t)nnz * sizeof(T), ts.st);
+    } else {
+        HIPCHK(schpf::launch_elog<T>(a.as<T>(), b.as<T>(), (int64_t)N * K, tt.as<T>(), ts.st));
+        HIPCHK(schpf::launch_elog<T>(c.as<T>(), d.as<T>(), (int64_t)G * K, tb.as<T>(), ts.st));
+        o.alloc((size_t)nnz * K * sizeof(T));
+        HIPCHK(schpf::launch_xphi_coo<T>(dx.as<T>(), dr.as<int>(), dc.as<int>(), tt.as<T>(), tb.as<T>(), nnz, K,
+                                         o.as<T>(), ts.st));
+        d2h(out, o, (size_t)nnz * K * sizeof(T), ts.st);
+    }
+}
+
+template <typename T>
+void shape_update(int64_t nnz, int K, const void *xphi, const int32_t *keep, int nkeep, double prior, void *out)
+{
+    check_indices(nnz, keep, nkeep, "keep");
+    std::vector<int32_t> order;
+    std::vector<int64_t> ptr;
+    schpf::counting_sort_positions(nnz, keep, nkeep, order, ptr);
+    TempStream ts;
+    DevBuf dx, dord, dptr, o;
+    h2d<T>(dx, xphi, (size_t)nnz * K, ts.st);
+    upload(dord, order, ts.st);
+    upload(dptr, ptr, ts.st);
+    o.alloc((size_t)nkeep * K * sizeof(T));
+    HIPCHK(schpf::launch_shape_update<T>(dx.as<T>(), dord.as<int>(), dptr.as<int64_t>(), nkeep, K, prior,
+                                         o.as<T>(), ts.st));
+    d2h(out, o, (size_t)nkeep * K * sizeof(T), ts.st);
+}
+
+template <typename T>
+void rate_update(int n, int m, int K, const void *ps, const void *pr, const void *os, const void *orr, void *out)
+{
+    if (K < 1 || K > 256) throw std::invalid_argument("nfactors must be in [1, 256]");
+    TempStream ts;
+    DevBuf a, b, c, d, part, S, o;
+    h2d<T>(a, ps, (size_t)n, ts.st); h2d<T>(b, pr, (size_t)n, ts.st);
+    h2d<T>(c, os, (size_t)m * K, ts.st); h2d<T>(d, orr, (size_t)m * K, ts.st);
+    const int rb = 256 / K;
+    const int nb = std::max(1, std::min((m + rb - 1) / rb, 512));
+    part.alloc((size_t)nb * K * sizeof(double));
+    S.alloc((size_t)K * sizeof(double));
+    HIPCHK(schpf::launch_ratio_colsum<T>(c.as<T>(), d.as<T>(), m, K, part.as<double>(), nb, ts.st));
+    HIPCHK(schpf::launch_colsum_reduce(part.as<double>(), nb, K, S.as<double>(), nullptr, 0, ts.st));
+    o.alloc((size_t)n * K * sizeof(T));
+    HIPCHK(schpf::launch_rate_update<T>(a.as<T>(), b.as<T>(), S.as<double>(), n, K, o.as<T>(), ts.st));
+    d2h(out, o, (size_t)n * K * sizeof(T), ts.st);
+}
+
+template <typename T> void capacity_rate(int n, int K, const void *shape, const void *rate, double prior, void *out)
+{
+    TempStream ts;
+    DevBuf a, b, o;
+    h2d<T>(a, shape, (size_t)n * K, ts.st); h2d<T>(b, rate, (size_t)n * K, ts.st);
+    o.alloc((size_t)n * sizeof(T));
+    HIPCHK(schpf::launch_capacity_rate<T>(a.as<T>(), b.as<T>(), n, K, prior, o.as<T>(), ts.st));
+    d2h(out, o, (size_t)n * sizeof(T), ts.st);
+}
+
+void special_array(bool gammaln, int64_t n, const double *x, double *out)
+{
+    TempStream ts;
+    DevBuf a, o;
+    h2d<double>(a, x, (size_t)n, ts.st);
+    o.alloc((size_t)n * sizeof(double));
+    if (gammaln) HIPCHK(schpf::launch_gammaln_array(a.as<double>(), n, o.as<double>(), ts.st));
+    else HIPCHK(schpf::launch_digamma_array(a.as<double>(), n, o.as<double>(), ts.st));
+    d2h(out, o, (size_t)n * sizeof(double), ts.st);
+}
+
+bool bad_dtype(int dtype) { return dtype != SCHPF_F32 && dtype != SCHPF_F64; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char *schpf_last_error(void) { return g_err.c_str(); }
+const char *schpf_version(void) { return "schpf_hip 0.1 (gfx950)"; }
+
+int schpf_device_count(int *count)
+{
+    return guarded([&] {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        *count = n;
+    });
+}
+
+int schpf_digamma(int64_t n, const double *x, double *out) { return guarded([&] { special_array(false, n, x, out); }); }
+int schpf_gammaln(int64_t n, const double *x, double *out) { return guarded([&] { special_array(true, n, x, out); }); }
+
+int schpf_xphi(int dtype, int64_t nnz, int N, int G, int K, const void *x, const int32_t *row, const int32_t *col,
+               const void *ths, const void *thr, const void *bes, const void *ber, void *out)
+{
+    if (bad_dtype(dtype)) return fail("dtype must be SCHPF_F32 or SCHPF_F64");
+    return guarded([&] {
+        if (dtype == SCHPF_F64) xphi_or_llh<double>(false, nnz, N, G, K, x, row, col, ths, thr, bes, ber, out);
+        else xphi_or_llh<float>(false, nnz, N, G, K, x, row, col, ths, thr, bes, ber, out);
+    });
+}
+int schpf_pois_llh_pointwise(int dtype, int64_t nnz, int N, int G, int K, const void *x, const int32_t *row,
+                             const int32_t *col, const void *ths, const void *thr, const void *bes,
+                             const void *ber, void *out)
+{
+    if (bad_dtype(dtype)) return fail("dtype must be SCHPF_F32 or SCHPF_F64");
+    return guarded([&] {
+        if (dtype == SCHPF_F64) xphi_or_llh<double>(true, nnz, N, G, K, x, row, col, ths, thr, bes, ber, out);
+        else xphi_or_llh<float>(true, nnz, N, G, K, x, row, col, ths, thr, bes, ber, out);
+    });
+}
+int schpf_shape_update(int dtype, int64_t nnz, int K, const void *xphi, const int32_t *keep, int nkeep,
+                       double prior, void *out)
+{
+    if (bad_dtype(dtype)) return fail("dtype must be SCHPF_F32 or SCHPF_F64");
+    return guarded([&] {
+        if (dtype == SCHPF_F64) shape_update<double>(nnz, K, xphi, keep, nkeep, prior, out);
+        else shape_update<float>(nnz, K, xphi, keep, nkeep, prior, out);
+    });
+}
+int schpf_rate_update(int dtype, int n, int m, int K, const void *ps, const void *pr, const void *os,
+                      const void *orr, void *out)
+{
+    if (bad_dtype(dtype)) return fail("dtype must be SCHPF_F32 or SCHPF_F64");
+    return guarded([&] {
+        if (dtype == SCHPF_F64) rate_update<double>(n, m, K, ps, pr, os, orr, out);
+        else rate_update<float>(n, m, K, ps, pr, os, orr, out);
+    });
+}
+int schpf_capacity_rate_update(int dtype, int n, int K, const void *shape, const void *rate, double prior,
+                               void *out)
+{
+    if (bad_dtype(dtype)) return fail("dtype must be SCHPF_F32 or SCHPF_F64");
+    return guarded([&] {
+        if (dtype == SCHPF_F64) capacity_rate<double>(n, K, shape, rate, prior, out);
+        else capacity_rate<float>(n, K, shape, rate, prior, out);
+    });
+}
+
+int schpf_create(schpf_ctx **out, int device, void *stream, int dtype, int ncells, int ngenes, int nfactors)
+{
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    if (bad_dtype(dtype)) return fail("dtype must be SCHPF_F32 or SCHPF_F64");
+    if (ncells < 1 || ngenes < 1) return fail("ncells and ngenes must be positive");
+    return guarded([&] {
+        int n = 0;
+        HIPCHK(hipGetDeviceCount(&n));
+        if (device < 0 || device >= n) throw std::invalid_argument("no such HIP device");
+        if (dtype == SCHPF_F64) *out = new Engine<double>(device, stream, dtype, ncells, ngenes, nfactors);
+        else *out = new Engine<float>(device, stream, dtype, ncells, ngenes, nfactors);
+    });
+}
+int schpf_destroy(schpf_ctx *ctx)
+{
+    return guarded([&] { delete ctx; });
+}
+
+#define CTX_CALL(body)                                       \
+    if (!ctx) return fail("ctx is NULL");                    \
+    return guarded([&] {                                     \
+        HIPCHK(hipSetDevice(ctx->device));                   \
+        body;                                                \
+    })
+
+int schpf_upload_coo(schpf_ctx *ctx, int64_t nnz, const int32_t *row, const int32_t *col, const void *val,
+                     int val_kind)
+{
+    CTX_CALL(ctx->upload_coo(nnz, row, col, val, val_kind));
+}
+int schpf_set_hypers(schpf_ctx *ctx, double a, double c, double bp, double dp)
+{
+    if (!(a > 0 && c > 0 && bp > 0 && dp > 0)) return fail("hyperparameters must be positive");
+    CTX_CALL(ctx->a = a; ctx->c = c; ctx->bp = bp; ctx->dp = dp);
+}
+int schpf_set_state(schpf_ctx *ctx, int which, const void *shape, const void *rate)
+{
+    CTX_CALL(ctx->set_state(which, shape, rate));
+}
+int schpf_get_state(schpf_ctx *ctx, int which, void *shape, void *rate)
+{
+    CTX_CALL(ctx->get_state(which, shape, rate));
+}
+int schpf_init_phi_host(schpf_ctx *ctx, const double *xphi) { CTX_CALL(ctx->init_phi_host(xphi)); }
+int schpf_init_phi_device(schpf_ctx *ctx, uint64_t seed) { CTX_CALL(ctx->init_phi_device(seed)); }
+int schpf_step(schpf_ctx *ctx, unsigned flags)
+{
+    if (flags & SCHPF_SHARDED) return fail("schpf_step is the single-GPU form; use step_local/step_finish");
+    CTX_CALL(ctx->step_local(flags); ctx->step_finish(flags));
+}
+int schpf_step_local(schpf_ctx *ctx, unsigned flags) { CTX_CALL(ctx->step_local(flags)); }
+int schpf_exchange_buffer(schpf_ctx *ctx, void **device_ptr, int64_t *count)
+{
+    CTX_CALL(ctx->exchange(device_ptr, count));
+}
+int schpf_step_finish(schpf_ctx *ctx, unsigned flags) { CTX_CALL(ctx->step_finish(flags)); }
+int schpf_loss_terms(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64_t *nnz)
+{
+    CTX_CALL(ctx->loss_terms(llh_sum, gammaln_sum, nnz));
+}
+int schpf_synchronize(schpf_ctx *ctx) { CTX_CALL(HIPCHK(hipStreamSynchronize(ctx->stream))); }
+
+int schpf_profile_enable(schpf_ctx *ctx, int enable) { CTX_CALL(ctx->prof.on = enable != 0); }
+int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
+{
+    CTX_CALL(
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 4; ++i) { ms[i] = 0.0; launches[i] = 0; }
+        for (auto &r : ctx->prof.recs) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+            ms[r.kind] += (double)t;
+            launches[r.kind]++;
+            ctx->prof.pool.push_back(r.a);
+            ctx->prof.pool.push_back(r.b);
+        }
+        ctx->prof.recs.clear());
+}
+int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]) { CTX_CALL(ctx->plan_info(info)); }
+
+int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                            int n_major, int n_minor, int lpc, int chunk_len, int n_windows,
+                            int32_t *out_major, int32_t *out_minor, float *out_val, int32_t *out_natid,
+                            int32_t *out_wave, int32_t *out_cptr, int64_t stats[4])
+{
+    return guarded([&] {
+        schpf::SweepPlanHost P;
+        schpf::build_sweep_plan(nnz, major, minor, val, n_major, n_minor, lpc, chunk_len, n_windows, false, P);
+        std::vector<int32_t> wave_of_slice((size_t)P.n_slices, -1);
+        for (int64_t w = 0; w < P.n_waves; ++w)
+            if (P.wave_slice[(size_t)w] >= 0) {
+                if (wave_of_slice[(size_t)P.wave_slice[(size_t)w]] != -1)
+                    throw std::logic_error("slice scheduled twice");
+                wave_of_slice[(size_t)P.wave_slice[(size_t)w]] = (int32_t)w;
+            }
+        int64_t n = 0;
+        for (int64_t s = 0; s < P.n_slices; ++s) {
+            if (wave_of_slice[(size_t)s] < 0) throw std::logic_error("slice never scheduled");
+            const uint32_t *base = P.entries.data() + (size_t)P.slice_off[(size_t)s] * 4;
+            for (int step = 0; step < P.slice_steps[(size_t)s]; ++step)
+                for (int slot = 0; slot < P.cpw; ++slot)
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t *e = base + ((size_t)step * P.cpw + slot) * 4 + (size_t)u * 2;
+                        float f;
+                        std::memcpy(&f, &e[1], 4);
+                        if (f == 0.0f) continue;
+                        if (n >= nnz) throw std::logic_error("plan stores more nonzeros than given");
+                        out_major[n] = P.chunk_major[(size_t)s * P.cpw + slot];
+                        out_minor[n] = (int32_t)e[0];
+                        out_val[n] = f;
+                        out_natid[n] = P.chunk_natid[(size_t)s * P.cpw + slot];
+                        out_wave[n] = wave_of_slice[(size_t)s];
+                        ++n;
+                    }
+        }
+        if (n != nnz) throw std::logic_error("plan lost nonzeros");
+        for (int m = 0; m <= n_major; ++m) out_cptr[m] = P.cptr[(size_t)m];
+        stats[0] = P.n_chunks; stats[1] = P.n_slices; stats[2] = P.n_waves;
+        stats[3] = (int64_t)P.entries.size() / 2;
+    });
+}
+
+}  // extern "C"

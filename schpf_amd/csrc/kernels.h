@@ -1,0 +1,86 @@
+// Kernel argument blocks and host-callable launchers (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace schpf {
+
+enum { MODE_PHI = 0, MODE_LLH = 1 };
+enum { SRC_NONE = 0, SRC_PARTIALS = 1, SRC_DENSE = 2 };
+
+template <typename T> struct SweepArgs {
+    const uint4 *entries;       // sliced-ELL nonzeros {minor0, val0, minor1, val1}
+    const int64_t *slice_off;   // [n_slices] in uint4 units
+    const int *slice_steps;     // [n_slices]
+    const int *chunk_major;     // [n_slices * CPW]
+    const int *chunk_natid;     // [n_slices * CPW]
+    const int *wave_slice;      // [n_waves]
+    const T *tab_major;         // [n_major, KP] exp-shifted E[log] (PHI) or E[x] (LLH)
+    const T *tab_minor;         // [n_minor, KP]
+    const T *log_major;         // [n_major, KP] E[log x] (fallback only)
+    const T *log_minor;         // [n_minor, KP]
+    T *partials;                // [n_chunks, KP]
+    T *extra;                   // [n_major, KP] fallback accumulator (zero unless flagged)
+    int *extra_flag;
+    double *wave_out;           // [n_waves] (LLH)
+    int K;
+};
+
+template <typename T> struct UpdateArgs {
+    int n, K, KP, rows_per_block;
+    const T *partials;          // SRC_PARTIALS: [n_chunks, KP]
+    const int *cptr;            //               [n + 1]
+    const T *dense;             // SRC_DENSE:    [n, K]
+    T *extra;                   // [n, KP] or null
+    const int *extra_flag;
+    double prior_shape;         // a or c
+    const T *cap_shape;         // xi / eta shape [n]
+    const T *cap_rate;          // xi / eta rate BEFORE this update [n]
+    const double *s_other;      // [K] sum over the other loading of E[x]
+    double cap_prior_rate;      // bp or dp
+    T *shape, *rate;            // [n, K] in/out
+    T *cap_rate_out;            // [n]
+    T *tab_e, *tab_log, *tab_exp;  // [n, KP]
+    double *colsum_part;        // [nblocks, K]
+};
+
+template <typename T>
+hipError_t launch_sweep(const SweepArgs<T> &a, int kl, int lpc, int mode, int64_t n_waves, hipStream_t st);
+template <typename T>
+hipError_t launch_random_phi(const SweepArgs<T> &a, int kl, int lpc, uint64_t seed, int major_is_cell,
+                             int64_t n_waves, hipStream_t st);
+template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
+hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
+                                int mirror_is_f32, hipStream_t st);
+template <typename T>
+hipError_t launch_combine_partials(const T *partials, const int *cptr, int n, int K, int KP, T *extra,
+                                   const int *extra_flag, T *out, hipStream_t st);
+hipError_t launch_sum_doubles(const double *v, int64_t n, double *out, hipStream_t st);
+hipError_t launch_gammaln_sum(const float *x, int64_t n, double *block_out, int nblocks, hipStream_t st);
+template <typename T>
+hipError_t launch_segment_sum(const double *xphi, const int *order, const int64_t *mptr, int n, int K, T *out,
+                              hipStream_t st);
+
+template <typename T> hipError_t launch_elog(const T *shape, const T *rate, int64_t n, T *out, hipStream_t st);
+template <typename T> hipError_t launch_ratio(const T *shape, const T *rate, int64_t n, T *out, hipStream_t st);
+template <typename T>
+hipError_t launch_xphi_coo(const T *x, const int *row, const int *col, const T *elt, const T *elb, int64_t nnz,
+                           int K, T *out, hipStream_t st);
+template <typename T>
+hipError_t launch_llh_coo(const T *x, const int *row, const int *col, const T *et, const T *eb, int64_t nnz,
+                          int K, T *out, hipStream_t st);
+template <typename T>
+hipError_t launch_shape_update(const T *xphi, const int *order, const int64_t *ptr, int n, int K, double prior,
+                               T *out, hipStream_t st);
+template <typename T>
+hipError_t launch_ratio_colsum(const T *shape, const T *rate, int m, int K, double *part, int nblocks,
+                               hipStream_t st);
+template <typename T>
+hipError_t launch_rate_update(const T *ps, const T *pr, const double *S, int n, int K, T *out, hipStream_t st);
+template <typename T>
+hipError_t launch_capacity_rate(const T *shape, const T *rate, int n, int K, double prior, T *out,
+                                hipStream_t st);
+hipError_t launch_digamma_array(const double *x, int64_t n, double *out, hipStream_t st);
+hipError_t launch_gammaln_array(const double *x, int64_t n, double *out, hipStream_t st);
+
+}  // namespace schpf

@@ -1,0 +1,62 @@
+// Sweep plan: the HBM layout of the sparse UMI matrix for one orientation.
+//
+// The CAVI responsibility pass touches every stored nonzero (cell i, gene g, count x)
+// once per orientation:  the CELL sweep accumulates into per-cell K-vectors (major =
+// cell, minor = gene; replaces the theta half of schpf/hpf_numba.py:128-156 driven by
+// schpf/scHPF_.py:709-710), the GENE sweep into per-gene K-vectors (major = gene,
+// minor = cell; scHPF_.py:699-700).  Both use the same layout, built here on the host:
+//
+//   * nonzeros are sorted by (major, minor); each major's run is cut into CHUNKS of at
+//     most `chunk_len` nonzeros that do not straddle a minor WINDOW (windows keep the
+//     gathered table slice of the minor side L2-resident; window w is worked on by the
+//     XCDs congruent to w);
+//   * chunks are ordered (window, length descending) and grouped CPW = 64 / LPC at a
+//     time into SLICES -- one slice is what one wavefront streams;
+//   * inside a slice nonzeros are stored step-major ("sliced ELL"): step p holds, for
+//     every chunk of the slice, two nonzeros packed as uint4 {minor0, val0, minor1,
+//     val1}; the 64 lanes of a wave therefore read one fully coalesced 16 B x CPW line
+//     per step.  Short chunks are padded with {0, 0.0f} (a zero count contributes
+//     nothing).
+//
+// A chunk's partial K-vector is written to row `natural id` of a partials matrix; the
+// natural ids of one major are consecutive (cptr), so the fused update kernel reduces
+// them in a fixed order: no atomics, run-to-run deterministic.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace schpf {
+
+struct SweepPlanHost {
+    int n_major = 0, n_minor = 0;
+    int lpc = 1;            // lanes per chunk
+    int cpw = 64;           // chunks per wave (= 64 / lpc)
+    int chunk_len = 0;      // max nonzeros per chunk (even)
+    int n_windows = 1;
+    int64_t nnz = 0;
+    int64_t n_chunks = 0;   // natural chunks (rows of the partials matrix)
+    int64_t n_slices = 0;
+    int64_t n_waves = 0;    // launch size in wavefronts (multiple of 4)
+    std::vector<uint32_t> entries;        // 4 words per (step, chunk-slot): see above
+    std::vector<int64_t> slice_off;       // [n_slices] offset into entries, in uint4 units
+    std::vector<int32_t> slice_steps;     // [n_slices] number of uint4 steps
+    std::vector<int32_t> chunk_major;     // [n_slices * cpw], -1 for an empty slot
+    std::vector<int32_t> chunk_natid;     // [n_slices * cpw]
+    std::vector<int32_t> wave_slice;      // [n_waves] slice id or -1 (XCD-aware order)
+    std::vector<int32_t> cptr;            // [n_major + 1] natural-chunk ranges per major
+    std::vector<int32_t> order;           // [nnz] sorted position -> position in the caller's COO
+    std::vector<int64_t> mptr;            // [n_major + 1] sorted-position ranges per major
+};
+
+// major/minor: int32 indices (already validated), val: float counts.
+// keep_order: also fill `order`/`mptr` (needed for the t=0 responsibilities upload).
+void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                      int n_major, int n_minor, int lpc, int chunk_len, int n_windows,
+                      bool keep_order, SweepPlanHost &out);
+
+// Stable counting sort of positions by key: order[j] = original position of the j-th
+// smallest key; ptr[k]..ptr[k+1] is the run of key k.
+void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vector<int32_t> &order,
+                             std::vector<int64_t> &ptr);
+
+}  // namespace schpf

@@ -1,0 +1,174 @@
+"""Device-resident CAVI engine: the state of scHPF._fit's loop kept in HBM.
+
+One `DeviceCAVI` = one GPU = the count matrix (both sweep plans), the four
+variational Gammas and their derived tables.  `step()` is the body of the loop at
+/root/reference/schpf/scHPF_.py:657-714; `mean_negative_pois_llh()` is the default
+loss (schpf/loss.py:142-168).  Nothing here computes on the CPU: it is a thin
+object around the C ABI in include/schpf_hip.h.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_NAMES = {"xi": _lib.XI, "theta": _lib.THETA, "eta": _lib.ETA, "beta": _lib.BETA}
+_VAL_KINDS = {np.dtype(np.int32): _lib.VAL_I32, np.dtype(np.int64): _lib.VAL_I64,
+              np.dtype(np.float32): _lib.VAL_F32, np.dtype(np.float64): _lib.VAL_F64}
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class DeviceCAVI(object):
+    """CAVI state on one MI355X.
+
+    Parameters
+    ----------
+    ncells, ngenes, nfactors : int
+        ncells is the number of local cells when cells are sharded over GPUs.
+    dtype : np.float64 or np.float32
+        model precision (scHPF(dtype=...), scHPF_.py:239).
+    device : int
+        HIP device ordinal.
+    stream : int or None
+        a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) to
+        enqueue on; None lets the library create its own stream.
+    """
+
+    def __init__(self, ncells, ngenes, nfactors, dtype=np.float64, device=0, stream=None):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.dtype = np.dtype(dtype)
+        if self.dtype == np.float64:
+            code = _lib.F64
+        elif self.dtype == np.float32:
+            code = _lib.F32
+        else:
+            raise TypeError("dtype must be float64 or float32")
+        self.ncells, self.ngenes, self.nfactors = int(ncells), int(ngenes), int(nfactors)
+        self.nnz = 0
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.schpf_create(ctypes.byref(handle), int(device),
+                                          ctypes.c_void_p(stream or 0), code,
+                                          self.ncells, self.ngenes, self.nfactors))
+        self._h = handle
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.schpf_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -------------------------------------------------------------------- inputs
+    def upload(self, X):
+        """X: scipy coo_matrix-like with .row, .col, .data (ncells x ngenes)."""
+        if tuple(X.shape) != (self.ncells, self.ngenes):
+            raise ValueError("X has shape %s, engine was created for %s"
+                             % (tuple(X.shape), (self.ncells, self.ngenes)))
+        data = np.ascontiguousarray(X.data)
+        if data.dtype not in _VAL_KINDS:
+            data = data.astype(np.float64)
+        row = np.ascontiguousarray(X.row, dtype=np.int32)
+        col = np.ascontiguousarray(X.col, dtype=np.int32)
+        _lib.check(self._lib.schpf_upload_coo(self._h, data.shape[0], _p(row), _p(col), _p(data),
+                                              _VAL_KINDS[data.dtype]))
+        self.nnz = int(data.shape[0])
+
+    def set_hypers(self, a, c, bp, dp):
+        _lib.check(self._lib.schpf_set_hypers(self._h, float(a), float(c), float(bp), float(dp)))
+
+    def _dims(self, name):
+        n = self.ncells if name in ("xi", "theta") else self.ngenes
+        return (n, self.nfactors) if name in ("theta", "beta") else (n,)
+
+    def set_gamma(self, name, vi_shape, vi_rate):
+        dims = self._dims(name)
+        s = np.ascontiguousarray(vi_shape, dtype=self.dtype)
+        r = np.ascontiguousarray(vi_rate, dtype=self.dtype)
+        if s.shape != dims or r.shape != dims:
+            raise ValueError("%s must have shape %s, got %s / %s" % (name, dims, s.shape, r.shape))
+        _lib.check(self._lib.schpf_set_state(self._h, _NAMES[name], _p(s), _p(r)))
+
+    def get_gamma(self, name):
+        dims = self._dims(name)
+        s = np.empty(dims, dtype=self.dtype)
+        r = np.empty(dims, dtype=self.dtype)
+        _lib.check(self._lib.schpf_get_state(self._h, _NAMES[name], _p(s), _p(r)))
+        return s, r
+
+    # ----------------------------------------------------------------- iteration
+    def init_phi_host(self, Xphi_data):
+        """t == 0 responsibilities drawn by the caller (scHPF_.py:652-655)."""
+        x = np.ascontiguousarray(Xphi_data, dtype=np.float64)
+        if x.shape != (self.nnz, self.nfactors):
+            raise ValueError("Xphi_data must be (nnz, nfactors)")
+        _lib.check(self._lib.schpf_init_phi_host(self._h, _p(x)))
+
+    def init_phi_device(self, seed):
+        _lib.check(self._lib.schpf_init_phi_device(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    @staticmethod
+    def _flags(freeze_genes, simultaneous, sharded=False):
+        return ((_lib.FREEZE_GENES if freeze_genes else 0) | (_lib.SIMULTANEOUS if simultaneous else 0)
+                | (_lib.SHARDED if sharded else 0))
+
+    def step(self, freeze_genes=False, simultaneous=False):
+        _lib.check(self._lib.schpf_step(self._h, self._flags(freeze_genes, simultaneous)))
+
+    def step_local(self, freeze_genes=False, simultaneous=False):
+        _lib.check(self._lib.schpf_step_local(self._h, self._flags(freeze_genes, simultaneous, True)))
+
+    def step_finish(self, freeze_genes=False, simultaneous=False):
+        _lib.check(self._lib.schpf_step_finish(self._h, self._flags(freeze_genes, simultaneous, True)))
+
+    def exchange_buffer(self):
+        """(device pointer, element count) of the buffer to all-reduce between
+        step_local and step_finish; elements have the model dtype."""
+        ptr, count = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(self._lib.schpf_exchange_buffer(self._h, ctypes.byref(ptr), ctypes.byref(count)))
+        return ptr.value, count.value
+
+    def loss_terms(self):
+        """(sum x log r - r, sum lgamma(x+1), nnz) over the local nonzeros."""
+        llh, gl, nnz = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._lib.schpf_loss_terms(self._h, ctypes.byref(llh), ctypes.byref(gl), ctypes.byref(nnz)))
+        return llh.value, gl.value, nnz.value
+
+    def mean_negative_pois_llh(self):
+        llh, gl, nnz = self.loss_terms()
+        return -(llh - gl) / nnz
+
+    def synchronize(self):
+        _lib.check(self._lib.schpf_synchronize(self._h))
+
+    # ----------------------------------------------------------------- reporting
+    def profile(self, enable=True):
+        _lib.check(self._lib.schpf_profile_enable(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_int64 * 4)()
+        _lib.check(self._lib.schpf_profile_read(self._h, ms, n))
+        keys = ("cell_sweep", "gene_sweep", "loss_sweep", "gamma_updates")
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(keys)}
+
+    def plan_info(self):
+        info = (ctypes.c_int64 * 12)()
+        _lib.check(self._lib.schpf_plan_info(self._h, info))
+        keys = ("KP", "KL", "LPC", "chunk_len", "windows_cell", "windows_gene", "n_chunks_cell",
+                "n_chunks_gene", "n_waves_cell", "n_waves_gene", "entry_slots_cell", "entry_slots_gene")
+        return dict(zip(keys, [int(v) for v in info]))

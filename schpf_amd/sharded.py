@@ -1,0 +1,82 @@
+"""Cells sharded over the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed layer; what it offers to shard on is
+the model itself: given beta/eta, cells are independent (schpf/scHPF_.py:706-714),
+and genes only need sums over cells (:699-703).  So rank p keeps a contiguous block
+of rows of X with its xi/theta slices and a replica of eta/beta, and one iteration is
+
+    step_local   both sweeps on the local rows; gene-side sums (G*K) and the local
+                 sum_i E[theta_ik] (K) are packed into one device buffer
+    all_reduce   ONE sum all-reduce of that buffer (torch.distributed; backend "nccl"
+                 is RCCL on ROCm)
+    step_finish  every rank applies the identical beta/eta update to its replica,
+                 then its own theta/xi update
+
+With freeze_genes (project) there is nothing to exchange.  The loss needs a second,
+3-scalar all-reduce on check iterations only.  The engine is duck-typed
+(step_local / step_finish / exchange_tensor / loss_terms) so the protocol is testable
+on CPU with the gloo backend and an oracle-backed engine (tests/test_sharded_cpu.py).
+"""
+import numpy as np
+
+__all__ = ["row_partition", "take_rows", "ShardedCAVI", "exchange_tensor_of"]
+
+
+def row_partition(X, world_size):
+    """Contiguous row ranges balanced by stored nonzeros.  Returns world_size+1 bounds."""
+    counts = np.bincount(X.row, minlength=X.shape[0]).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    targets = cum[-1] * np.arange(1, world_size) / world_size
+    inner = np.searchsorted(cum, targets, side="left")
+    bounds = np.concatenate([[0], inner, [X.shape[0]]]).astype(np.int64)
+    return np.maximum.accumulate(bounds)
+
+
+def take_rows(X, lo, hi):
+    """Rows [lo, hi) of a COO matrix as a COO matrix with local row indices, stored order
+    preserved; also returns the positions of the kept nonzeros in X."""
+    from scipy.sparse import coo_matrix
+    keep = np.flatnonzero((X.row >= lo) & (X.row < hi))
+    sub = coo_matrix((X.data[keep], (X.row[keep] - lo, X.col[keep])), shape=(int(hi - lo), X.shape[1]))
+    return sub, keep
+
+
+class _DevicePointer(object):
+    """Minimal __cuda_array_interface__ carrier so torch can view library-owned HBM."""
+
+    def __init__(self, ptr, count, dtype):
+        self.__cuda_array_interface__ = {
+            "shape": (int(count),), "typestr": np.dtype(dtype).str, "data": (int(ptr), False),
+            "version": 2, "strides": None}
+
+
+def exchange_tensor_of(engine, device_index):
+    """torch view (no copy) of a DeviceCAVI's exchange buffer."""
+    import torch
+    ptr, count = engine.exchange_buffer()
+    return torch.as_tensor(_DevicePointer(ptr, count, engine.dtype), device="cuda:%d" % device_index)
+
+
+class ShardedCAVI(object):
+    """Drives one rank's engine through the sharded iteration."""
+
+    def __init__(self, engine, exchange_tensor, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.engine = engine
+        self.exchange = exchange_tensor
+        self.group = group
+
+    def step(self, freeze_genes=False, simultaneous=False):
+        self.engine.step_local(freeze_genes=freeze_genes, simultaneous=simultaneous)
+        if not freeze_genes:
+            self.dist.all_reduce(self.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.engine.step_finish(freeze_genes=freeze_genes, simultaneous=simultaneous)
+
+    def mean_negative_pois_llh(self):
+        import torch
+        llh, gl, nnz = self.engine.loss_terms()
+        t = torch.tensor([llh, gl, float(nnz)], dtype=torch.float64, device=self.exchange.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        llh, gl, nnz = t.tolist()
+        return -(llh - gl) / nnz

@@ -1,0 +1,101 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/schpf_hip.h declares, refuses to compute without a GPU, and its host-side
+plan builder stores every nonzero exactly once in a consistent layout."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synthetic_counts
+from schpf_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "schpf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(schpf_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), "libschpf_hip.so does not export %s" % name
+    # and the binding table covers the header
+    bound = set(_lib.SIGNATURES) | set(_lib.STRING_FUNCS)
+    assert set(names) == bound
+
+
+def test_version_and_error_string():
+    lib = _lib.load()
+    assert b"gfx950" in lib.schpf_version()
+    status = lib.schpf_create(None, 0, None, 1, 10, 10, 2)
+    assert status != 0
+    assert b"NULL" in lib.schpf_last_error()
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback():
+    """Without a GPU the product raises; it never computes on the host."""
+    from schpf_amd import hpf_hip, DeviceCAVI
+    with pytest.raises(_lib.SchpfHipError):
+        DeviceCAVI(10, 10, 2)
+    with pytest.raises(_lib.SchpfHipError):
+        hpf_hip.psi(1.0)
+
+
+def expand(major, minor, val, n_major, n_minor, lpc, chunk_len, n_windows):
+    lib = _lib.load()
+    nnz = len(val)
+    major = np.ascontiguousarray(major, np.int32)
+    minor = np.ascontiguousarray(minor, np.int32)
+    val = np.ascontiguousarray(val, np.float32)
+    om = np.empty(nnz, np.int32); on = np.empty(nnz, np.int32); ov = np.empty(nnz, np.float32)
+    onat = np.empty(nnz, np.int32); ow = np.empty(nnz, np.int32)
+    cptr = np.empty(n_major + 1, np.int32)
+    stats = (ctypes.c_int64 * 4)()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _lib.check(lib.schpf_debug_plan_expand(nnz, p(major), p(minor), p(val), n_major, n_minor, lpc,
+                                           chunk_len, n_windows, p(om), p(on), p(ov), p(onat), p(ow),
+                                           p(cptr), stats))
+    return om, on, ov, onat, ow, cptr, [int(s) for s in stats]
+
+
+@pytest.mark.parametrize("lpc,chunk_len,n_windows", [(1, 16, 1), (2, 32, 2), (4, 8, 8), (8, 64, 16), (1, 2, 4)])
+def test_plan_roundtrip(lpc, chunk_len, n_windows):
+    X = synthetic_counts(257, 1031, 0.04, seed=5)
+    perm = np.random.RandomState(0).permutation(X.nnz)       # unsorted COO on purpose
+    row, col, val = X.row[perm], X.col[perm], X.data[perm].astype(np.float32)
+    for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
+        om, on, ov, onat, ow, cptr, stats = expand(major, minor, val, nM, nm, lpc, chunk_len, n_windows)
+        # every nonzero exactly once
+        key_in = np.sort(major.astype(np.int64) * nm + minor)
+        key_out = np.sort(om.astype(np.int64) * nm + on)
+        assert np.array_equal(key_in, key_out)
+        order_in = np.lexsort((minor, major)); order_out = np.lexsort((on, om))
+        assert np.array_equal(val[order_in], ov[order_out])
+        # partial rows: chunk c belongs to exactly one major, ids of a major are cptr[m]..cptr[m+1]
+        assert cptr[0] == 0 and cptr[-1] == stats[0]
+        assert np.all(onat >= cptr[om]) and np.all(onat < cptr[om + 1])
+        # chunk length bound and one window per chunk
+        counts = np.bincount(onat, minlength=stats[0])
+        assert counts.max() <= chunk_len and counts.min() >= 1
+        wwidth = (nm + n_windows - 1) // n_windows
+        win = on // wwidth
+        first = np.full(stats[0], -1); first[onat] = win
+        assert np.array_equal(first[onat], win)
+        # XCD-aware schedule: workgroup b (4 waves) runs on XCD b % 8 and only serves windows
+        # congruent to it modulo min(n_windows, 8)
+        g = min(n_windows, 8)
+        xcd = (ow // 4) % 8
+        assert np.array_equal(xcd % g, win % g)
+        assert stats[2] % 32 == 0
+
+
+def test_plan_empty_rows_and_single_nonzero():
+    om, on, ov, onat, ow, cptr, stats = expand([3], [2], [7.0], 6, 5, 1, 16, 1)
+    assert (om[0], on[0], ov[0]) == (3, 2, 7.0)
+    assert list(cptr) == [0, 0, 0, 0, 1, 1, 1] and stats[0] == 1

@@ -1,0 +1,272 @@
+"""GPU parity of the device-resident CAVI engine and of scHPF.fit()/project() built on
+it, against the CPU oracle and the golden traces produced by the reference.
+
+Stated tolerances (DESIGN.md "parity"): after one iteration from identical state,
+rtol 1e-11 (f64) / 2e-5 (f32) on every shape/rate; whole fits from identical seeds:
+per-check loss rtol 1e-9 (f64) / 1e-4 (f32), final theta/beta/xi/eta rtol 1e-6 (f64) /
+2e-2 (f32, 40-60 iterations of f32 round-off through a non-convex iteration).
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from conftest import load_golden, golden_coo, synthetic_counts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import schpf_amd
+    from schpf_amd import _lib
+    _lib.require_gpu()
+    return schpf_amd
+
+
+def random_state(oracle, X, K, dtype, seed, a=0.3, c=0.3, ap=1.0, cp=1.0):
+    np.random.seed(seed)
+    bp, dp, st = oracle.setup_state(X, K, np.dtype(dtype), a, ap, c, cp)
+    st.xi_shape[:] = ap + K * a
+    st.eta_shape[:] = cp + K * c
+    return bp, dp, st
+
+
+def load_engine(amd, X, K, dtype, st, a, c, bp, dp):
+    eng = amd.DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype)
+    eng.upload(X)
+    eng.set_hypers(a, c, bp, dp)
+    eng.set_gamma("xi", st.xi_shape, st.xi_rate)
+    eng.set_gamma("theta", st.theta_shape, st.theta_rate)
+    eng.set_gamma("eta", st.eta_shape, st.eta_rate)
+    eng.set_gamma("beta", st.beta_shape, st.beta_rate)
+    return eng
+
+
+def compare_state(eng, st, rtol):
+    for name in ("xi", "theta", "eta", "beta"):
+        s, r = eng.get_gamma(name)
+        assert_allclose(s, getattr(st, name + "_shape"), rtol=rtol, err_msg=name + " shape")
+        assert_allclose(r, getattr(st, name + "_rate"), rtol=rtol, err_msg=name + " rate")
+
+
+CASES = [  # (ncells, ngenes, density, K)
+    (300, 1000, 0.03, 4),
+    (513, 777, 0.05, 20),
+    (1000, 400, 0.10, 10),
+    (200, 300, 0.20, 50),
+    (64, 90, 0.30, 1),
+    (150, 200, 0.10, 100),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
+def test_iterations_match_oracle(amd, oracle, dtype, case, flags):
+    N, G, dens, K = case
+    X = synthetic_counts(N, G, dens, seed=N + K)
+    a, c = 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=K)
+    f32 = np.dtype(dtype) == np.float32
+    with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+        loss0 = eng.mean_negative_pois_llh()
+        want0 = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                              st.beta_shape, st.beta_rate)
+        assert_allclose(loss0, want0, rtol=2e-6 if f32 else 1e-12)
+        for it in range(3):
+            eng.step(**flags)
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp, **flags)
+            compare_state(eng, st, rtol=(2e-5 * (it + 1)) if f32 else 1e-11)
+        loss = eng.mean_negative_pois_llh()
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                             st.beta_shape, st.beta_rate)
+        assert_allclose(loss, want, rtol=1e-5 if f32 else 1e-11)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_random_phi_first_iteration_matches_oracle(amd, oracle, dtype):
+    """t == 0: responsibilities drawn on the host (reference scHPF_.py:652-655)."""
+    X = synthetic_counts(300, 500, 0.05, seed=3)
+    K, a, c = 6, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=1)
+    xphi = X.data[:, None] * np.random.dirichlet(np.ones(K), X.nnz)
+    with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+        eng.init_phi_host(xphi)
+        eng.step()
+        st64 = st.cast(np.float64)
+        oracle.cavi_iteration(X.data, X.row, X.col, st64, a, c, bp, dp, xphi=xphi)
+        compare_state(eng, st64.cast(dtype), rtol=1e-6 if np.dtype(dtype) == np.float32 else 1e-12)
+
+
+def test_device_random_phi_is_a_valid_start(amd, oracle):
+    """Device-generated t=0 responsibilities: each nonzero's phi sums to one, so
+    sum_k (shape - prior) over cells == over genes == sum of counts; cell and gene sweeps
+    regenerate the same draws (cross-checked through the k-marginals)."""
+    X = synthetic_counts(400, 300, 0.08, seed=9)
+    K, a, c = 8, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=2)
+    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+        eng.init_phi_device(1234)
+        eng.step()
+        ths, _ = eng.get_gamma("theta")
+        bes, _ = eng.get_gamma("beta")
+    assert_allclose((ths - a).sum(), X.data.sum(), rtol=1e-12)
+    assert_allclose((bes - c).sum(), X.data.sum(), rtol=1e-12)
+    assert_allclose((ths - a).sum(0), (bes - c).sum(0), rtol=1e-12)
+    assert_allclose((ths - a).sum(1), np.asarray(X.sum(1)).ravel(), rtol=1e-12)
+    assert np.all(ths > a * 0.999) and np.all(bes >= c)
+
+
+def test_underflow_fallback_matches_log_domain_oracle(amd, oracle):
+    """Factors whose E[log] differ by thousands make the product form underflow; the
+    kernel must fall back to the reference's max-shifted form (hpf_numba.py:98-112)."""
+    X = synthetic_counts(120, 150, 0.15, seed=21)
+    K, a, c = 4, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=5)
+    # cell i strongly prefers factor i%K, gene g factor (g+1)%K: shapes 1e-4 elsewhere
+    st.theta_shape[:] = 1e-4
+    st.beta_shape[:] = 1e-4
+    st.theta_shape[np.arange(120), np.arange(120) % K] = 5.0
+    st.beta_shape[np.arange(150), (np.arange(150) + 1) % K] = 5.0
+    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+        eng.step()
+        oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+        compare_state(eng, st, rtol=1e-10)
+        eng.step()      # and the fallback accumulators were cleaned up
+        oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+        compare_state(eng, st, rtol=1e-10)
+
+
+def test_empty_rows_and_columns_keep_the_prior(amd, oracle):
+    """The reference's own test matrix has 77 all-zero genes; shapes stay at the prior."""
+    g = load_golden("pbmc_like_data.npz")
+    X = golden_coo(g)
+    K, a, c = 5, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=0)
+    empty = np.asarray(X.sum(0)).ravel() == 0
+    assert empty.sum() == 77
+    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+        eng.step()
+        bes, _ = eng.get_gamma("beta")
+        assert np.all(bes[empty] == c)
+        oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+        compare_state(eng, st, rtol=1e-11)
+
+
+FITS = [
+    ("fit_data_k5_s0_f64.npz", np.float64, {}),
+    ("fit_data_k5_s1_f64.npz", np.float64, {}),
+    ("fit_conf_k4_s0_f64.npz", np.float64, {}),
+    ("fit_data_k5_s0_f64_simul.npz", np.float64, {"beta_theta_simultaneous": True}),
+    ("fit_data_k5_s0_f64_single.npz", np.float64, {"single_process": True}),
+    ("fit_data_k5_s0_f32.npz", np.float32, {}),
+    ("fit_conf_k4_s0_f32.npz", np.float32, {}),
+]
+
+
+@pytest.mark.parametrize("fname,dtype,kw", FITS)
+def test_fit_reproduces_reference_trace(amd, fname, dtype, kw):
+    """scHPF.fit() from the reference's seed reproduces the reference's run: same bp/dp,
+    same number of loss checks (same stop decision), same losses, same final model."""
+    from schpf import scHPF
+    g = load_golden(fname)
+    X = golden_coo(g)
+    np.random.seed(int(g["seed"]))
+    model = scHPF(int(g["nfactors"]), dtype=dtype, max_iter=int(g["max_iter"]), verbose=False)
+    model.fit(X, **kw)
+    f32 = np.dtype(dtype) == np.float32
+    assert model.bp == float(g["bp"]) and model.dp == float(g["dp"])
+    assert len(model.loss) == len(g["loss"])
+    assert_allclose(model.loss, g["loss"], rtol=1e-4 if f32 else 1e-9)
+    for name in ("xi", "theta", "eta", "beta"):
+        got = getattr(model, name)
+        assert got.vi_shape.dtype == np.dtype(dtype)
+        assert_allclose(got.vi_shape, g[name + "_shape"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
+        assert_allclose(got.vi_rate, g[name + "_rate"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
+    assert_allclose(model.cell_score(), (g["theta_shape"] / g["theta_rate"])
+                    * (g["xi_shape"] / g["xi_rate"])[:, None], rtol=2e-2 if f32 else 1e-6)
+
+
+def test_project_reproduces_reference_trace(amd):
+    from schpf import load_model
+    import os
+    from conftest import GOLDEN
+    g = load_golden("project_data_k5_f64.npz")
+    X = golden_coo(g)
+    model = load_model(os.path.join(GOLDEN, "ref_model_f64.joblib"))   # written by the reference
+    model.verbose = False
+    beta_before = model.beta.vi_shape.copy()
+    np.random.seed(int(g["seed"]))
+    proj = model.project(X, max_iter=20)
+    assert len(proj.loss) == len(g["loss"])
+    assert_allclose(proj.loss, g["loss"], rtol=1e-9)
+    assert_allclose(proj.theta.vi_shape, g["theta_shape"], rtol=1e-6)
+    assert_allclose(proj.theta.vi_rate, g["theta_rate"], rtol=1e-6)
+    assert_allclose(proj.xi.vi_rate, g["xi_rate"], rtol=1e-6)
+    assert proj.beta == model.beta and np.array_equal(model.beta.vi_shape, beta_before)
+    assert proj.bp == model.bp
+    # replace=True returns the loss and swaps xi/theta in place of the model's
+    np.random.seed(int(g["seed"]))
+    loss = model.project(X, max_iter=20, replace=True)
+    assert_allclose(loss, g["loss"], rtol=1e-9)
+    assert model.theta.dims == (40, 5)
+
+
+def test_custom_loss_and_checkstep_receive_host_gammas(amd):
+    from schpf import scHPF, HPF_Gamma
+    import schpf.loss as ls
+    g = load_golden("fit_data_k5_s0_f64.npz")
+    X = golden_coo(g)
+    seen = []
+
+    def checkstep(bp, dp, xi, eta, theta, beta, t):
+        assert isinstance(theta, HPF_Gamma) and theta.dims == (100, 5)
+        seen.append(t)
+
+    np.random.seed(0)
+    model = scHPF(5, max_iter=25, verbose=False)
+    model.fit(X, loss_function=ls.loss_function_for_data(ls.mean_negative_pois_llh, X),
+              checkstep_function=checkstep)
+    assert seen == [0, 10, 20]
+    assert_allclose(model.loss, g["loss"][:3], rtol=1e-9)
+
+
+def test_mass_conservation_at_benchmark_shape(amd, oracle):
+    """Size-independent property at BASELINE config C2 (10k x 5k, 3 %, K=10): every
+    nonzero's responsibilities sum to one, so after any iteration
+    sum_k (theta.shape - a)[i,:] = row sum of X and sum_k (beta.shape - c)[g,:] = column sum,
+    and both k-marginals agree (the cell sweep and the gene sweep saw the same phi)."""
+    X = synthetic_counts(10000, 5000, 0.03, seed=42)
+    K, a, c = 10, 0.3, 0.3
+    for dtype, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
+        bp, dp, st = random_state(oracle, X, K, dtype, seed=0)
+        with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+            for _ in range(3):
+                eng.step()
+            ths, thr = eng.get_gamma("theta")
+            bes, ber = eng.get_gamma("beta")
+            loss = eng.mean_negative_pois_llh()
+        rows = np.asarray(X.sum(1)).ravel(); cols = np.asarray(X.sum(0)).ravel()
+        assert_allclose((ths.astype(np.float64) - a).sum(1), rows, rtol=tol, atol=tol)
+        assert_allclose((bes.astype(np.float64) - c).sum(1), cols, rtol=tol, atol=tol * 10)
+        assert_allclose((ths.astype(np.float64) - a).sum(0), (bes.astype(np.float64) - c).sum(0), rtol=tol * 10)
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, ths, thr, bes, ber, nthreads=8)
+        assert_allclose(loss, want, rtol=1e-5 if dtype == np.float32 else 1e-11)
+        assert np.all(np.isfinite(ths)) and np.all(thr > 0) and np.all(ber > 0)
+
+
+def test_engine_argument_errors(amd):
+    X = synthetic_counts(50, 60, 0.1)
+    with pytest.raises(ValueError):
+        amd.DeviceCAVI(50, 60, 300)                       # nfactors > 256
+    with amd.DeviceCAVI(50, 60, 3) as eng:
+        with pytest.raises(Exception):
+            eng.step()                                    # nothing uploaded
+        with pytest.raises(ValueError):
+            eng.upload(synthetic_counts(51, 60, 0.1))     # wrong shape
+        bad = X.copy(); bad.data = bad.data.astype(np.float64); bad.data[0] = 0.5 + 2 ** -30
+        with pytest.raises(ValueError):
+            eng.upload(bad)                               # not exactly representable in f32
+        eng.upload(X)
+        with pytest.raises(ValueError):
+            eng.set_gamma("theta", np.ones((50, 2)), np.ones((50, 2)))
