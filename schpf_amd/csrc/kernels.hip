@@ -603,7 +603,8 @@ __global__ __launch_bounds__(256) void gammaln_array_kernel(const double *__rest
 }
 
 // ------------------------------------------------------------------------ launchers
-static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+// never a zero-sized grid: every kernel bounds-checks, an empty problem launches one idle block
+static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 255) / 256) : 1u; }
 
 template <typename T, int KL, int LPC>
 static hipError_t launch_sweep_t(const SweepArgs<T> &a, int mode, int64_t n_waves, hipStream_t st)
