@@ -138,7 +138,7 @@ struct ScopedTimer {
 // ------------------------------------------------------------------------------------
 struct schpf_ctx {
     int device = 0, dtype = SCHPF_F64, N = 0, G = 0, K = 0;
-    int KP = 0, KL = 0, LPC = 1;
+    int KP = 0, KL = 0, LPC = 1, NV = 1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     virtual ~schpf_ctx() {}
@@ -204,25 +204,31 @@ template <typename T> struct Engine final : schpf_ctx {
         if (own_stream) (void)hipStreamDestroy(stream);
     }
 
+    // Row layout of the gathered tables: KP = NV * LPC * VEC values (VEC = values per 16 B).
+    // One gather instruction makes a group's LPC lanes read LPC*16 contiguous bytes; the L1
+    // path is charged per 64-byte sector touched, so the cost model is
+    //   accesses per nonzero = NV * max(1, LPC/4)
+    // and the (LPC, NV) with the fewest accesses wins (ties: the earlier LPC in the list).
     void choose_config()
     {
         if (K < 1 || K > 256) throw std::invalid_argument("nfactors must be in [1, 256]");
-        const bool f64 = sizeof(T) == 8;
-        int lpc = env_int("SCHPF_LPC", 0);
-        if (!lpc) {
-            const int per_lane = f64 ? 12 : 24;  // K values one lane keeps three copies of
-            lpc = 1;
-            while (lpc < 8 && (K + lpc - 1) / lpc > per_lane) lpc *= 2;
+        const int vec = 16 / (int)sizeof(T);
+        const int nvec = (K + vec - 1) / vec;
+        static const int nv_ok[] = {1, 2, 3, 4, 5, 6, 8};
+        static const int lpc_order[] = {4, 8, 2, 16, 1};
+        const int force_lpc = env_int("SCHPF_LPC", 0);
+        int best_lpc = 0, best_nv = 0, best_cost = 1 << 30;
+        for (int lpc : lpc_order) {
+            if (force_lpc && lpc != force_lpc) continue;
+            const int need = (nvec + lpc - 1) / lpc;
+            int nv = 0;
+            for (int v : nv_ok) if (v >= need) { nv = v; break; }
+            if (!nv) continue;
+            const int cost = nv * std::max(1, lpc / 4);
+            if (cost < best_cost) { best_cost = cost; best_lpc = lpc; best_nv = nv; }
         }
-        if (lpc != 1 && lpc != 2 && lpc != 4 && lpc != 8) throw std::invalid_argument("SCHPF_LPC must be 1,2,4,8");
-        const int need = (K + lpc - 1) / lpc;
-        static const int kl_f32[] = {4, 8, 12, 16, 20, 24, 32};
-        static const int kl_f64[] = {2, 4, 6, 8, 10, 12, 16, 20, 24, 32};
-        int kl = 0;
-        if (f64) { for (int v : kl_f64) if (v >= need) { kl = v; break; } }
-        else { for (int v : kl_f32) if (v >= need) { kl = v; break; } }
-        if (!kl) throw std::invalid_argument("nfactors too large for this lanes-per-chunk setting");
-        LPC = lpc; KL = kl; KP = kl * lpc;
+        if (!best_lpc) throw std::invalid_argument("SCHPF_LPC must be one of 1,2,4,8,16 and fit nfactors");
+        LPC = best_lpc; NV = best_nv; KL = NV * vec; KP = KL * LPC;
     }
 
     static int pick_windows(size_t table_bytes, const char *envname)
@@ -443,9 +449,9 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         need_coo();
         auto ac = sweep_args(cell, th_exp, be_exp, th_log, be_log, extra_cell, 0);
-        HIPCHK(schpf::launch_random_phi<T>(ac, KL, LPC, seed, 1, cell.n_waves, stream));
+        HIPCHK(schpf::launch_random_phi<T>(ac, NV, LPC, seed, 1, cell.n_waves, stream));
         auto ag = sweep_args(gene, be_exp, th_exp, be_log, th_log, extra_gene, 1);
-        HIPCHK(schpf::launch_random_phi<T>(ag, KL, LPC, seed, 0, gene.n_waves, stream));
+        HIPCHK(schpf::launch_random_phi<T>(ag, NV, LPC, seed, 0, gene.n_waves, stream));
         pending_init = 2;
     }
 
@@ -459,13 +465,13 @@ template <typename T> struct Engine final : schpf_ctx {
             {
                 ScopedTimer tm(prof, stream, 0);
                 auto ac = sweep_args(cell, th_exp, be_exp, th_log, be_log, extra_cell, 0);
-                HIPCHK(schpf::launch_sweep<T>(ac, KL, LPC, schpf::MODE_PHI, cell.n_waves, stream));
+                HIPCHK(schpf::launch_sweep<T>(ac, NV, LPC, schpf::MODE_PHI, cell.n_waves, stream));
                 tm.stop();
             }
             if (!freeze) {
                 ScopedTimer tm(prof, stream, 1);
                 auto ag = sweep_args(gene, be_exp, th_exp, be_log, th_log, extra_gene, 1);
-                HIPCHK(schpf::launch_sweep<T>(ag, KL, LPC, schpf::MODE_PHI, gene.n_waves, stream));
+                HIPCHK(schpf::launch_sweep<T>(ag, NV, LPC, schpf::MODE_PHI, gene.n_waves, stream));
                 tm.stop();
             }
         }
@@ -554,7 +560,7 @@ template <typename T> struct Engine final : schpf_ctx {
         refresh_tables();
         ScopedTimer tm(prof, stream, 2);
         auto ac = sweep_args(cell, th_e, be_e, th_log, be_log, extra_cell, 0);
-        HIPCHK(schpf::launch_sweep<T>(ac, KL, LPC, schpf::MODE_LLH, cell.n_waves, stream));
+        HIPCHK(schpf::launch_sweep<T>(ac, NV, LPC, schpf::MODE_LLH, cell.n_waves, stream));
         HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(), cell.n_waves, scalars.as<double>(), stream));
         tm.stop();
         double h = 0.0;

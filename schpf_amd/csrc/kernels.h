@@ -45,9 +45,9 @@ template <typename T> struct UpdateArgs {
 };
 
 template <typename T>
-hipError_t launch_sweep(const SweepArgs<T> &a, int kl, int lpc, int mode, int64_t n_waves, hipStream_t st);
+hipError_t launch_sweep(const SweepArgs<T> &a, int nv, int lpc, int mode, int64_t n_waves, hipStream_t st);
 template <typename T>
-hipError_t launch_random_phi(const SweepArgs<T> &a, int kl, int lpc, uint64_t seed, int major_is_cell,
+hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t seed, int major_is_cell,
                              int64_t n_waves, hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,

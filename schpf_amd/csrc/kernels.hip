@@ -5,13 +5,8 @@
 // (schpf/scHPF_.py:657-714).  Wave = 64 lanes everywhere; no MFMA (the path has
 // no dense contraction); the roofline that bounds it is HBM / L2 gather.
 //
-// Algebra used by the fused sweeps (DESIGN.md "restatement"):
-//   phi_k = exp(Elt[i,k] + Elb[g,k]) / sum_k(...)  (hpf_numba.py:97-112)
-//         = Et[i,k] * Eb[g,k] / sum_k Et[i,k] Eb[g,k],
-//   Et[i,k] = exp(Elt[i,k] - max_k Elt[i,:]),  Eb likewise per gene,
-// so exp() is evaluated (N + G) * K times per iteration instead of nnz * K, and
-// X*phi (nnz x K, hpf_numba.py:97) is never materialised:
-//   sum_g x phi_k = Et[i,k] * sum_g (x / s_ig) Eb[g,k],   s_ig = sum_k Et Eb.
+// This file: the fused Gamma update, the reductions, the t=0 host-responsibilities path
+// and the stateless operator mirrors.  The sweep kernels are in sweep_impl.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -39,185 +34,6 @@ __device__ __forceinline__ double dev_digamma(double x)
     p = p * z - 8.33333333333333333333E-3;
     p = p * z + 8.33333333333333333333E-2;
     return log(x) - 0.5 / x - z * p - w;
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// streamed once per sweep: keep it out of the way of the gathered tables in L2
-__device__ __forceinline__ uint4 stream_load(const uint4 *p)
-{
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-template <typename T> struct Tiny;
-template <> struct Tiny<double> { static __device__ __forceinline__ double v() { return 1e-280; } };
-template <> struct Tiny<float> { static __device__ __forceinline__ float v() { return 1e-30f; } };
-
-template <typename T, int LPC> __device__ __forceinline__ T group_sum(T v)
-{
-#pragma unroll
-    for (int m = 1; m < LPC; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-template <typename T, int LPC> __device__ __forceinline__ T group_max(T v)
-{
-#pragma unroll
-    for (int m = 1; m < LPC; m <<= 1) {
-        T o = __shfl_xor(v, m, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-// KL contiguous values, 16-byte vector loads (rows are KP*sizeof(T) = multiple of 16 B).
-template <int KL> __device__ __forceinline__ void load_row(const float *__restrict__ p, float (&v)[KL])
-{
-#pragma unroll
-    for (int q = 0; q < KL / 4; ++q) {
-        float4 t = reinterpret_cast<const float4 *>(p)[q];
-        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-    }
-}
-template <int KL> __device__ __forceinline__ void load_row(const double *__restrict__ p, double (&v)[KL])
-{
-#pragma unroll
-    for (int q = 0; q < KL / 2; ++q) {
-        double2 t = reinterpret_cast<const double2 *>(p)[q];
-        v[2 * q] = t.x; v[2 * q + 1] = t.y;
-    }
-}
-template <int KL> __device__ __forceinline__ void store_row(float *__restrict__ p, const float (&v)[KL])
-{
-#pragma unroll
-    for (int q = 0; q < KL / 4; ++q)
-        reinterpret_cast<float4 *>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-template <int KL> __device__ __forceinline__ void store_row(double *__restrict__ p, const double (&v)[KL])
-{
-#pragma unroll
-    for (int q = 0; q < KL / 2; ++q)
-        reinterpret_cast<double2 *>(p)[q] = make_double2(v[2 * q], v[2 * q + 1]);
-}
-
-// ------------------------------------------------------------------------ the sweep
-// One wavefront streams one slice of the plan (plan.h).  A group of LPC adjacent lanes
-// owns one chunk (<= chunk_len nonzeros of one major row) and KL = KP / LPC factors
-// each; the major's K-vector and the K accumulators live in registers, the minor's
-// K-vector is gathered per nonzero (L2-resident window of the table).
-//
-// MODE_PHI : acc_k += (x / s) * Eb[minor,k];   out row = acc_k * Et[major,k]
-//            = this chunk's share of sum x*phi_k (hpf_numba.py:97-112 fused with
-//            :152-155).  Numerically degenerate nonzeros (s underflows) take the
-//            reference's max-shifted log-domain form from the Elog tables and go to
-//            `extra` with atomics (rare; flagged).
-// MODE_LLH : sum over the chunk of x*log(r) - r, r = sum_k E[theta]E[beta]
-//            (hpf_numba.py:43-50 minus the constant gammaln term); one double per wave.
-template <typename T, int KL, int LPC, int MODE>
-__global__ __launch_bounds__(256) void sweep_kernel(SweepArgs<T> a)
-{
-    constexpr int CPW = 64 / LPC;
-    constexpr int KP = KL * LPC;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int slice = a.wave_slice[wave];
-    if (slice < 0) {
-        if (MODE == MODE_LLH && (threadIdx.x & 63) == 0) a.wave_out[wave] = 0.0;
-        return;
-    }
-    const int lane = threadIdx.x & 63;
-    const int slot = lane / LPC;
-    const int sub = lane % LPC;
-    const int major = a.chunk_major[(size_t)slice * CPW + slot];
-    const bool live = major >= 0;
-
-    T tm[KL];
-    T acc[KL];
-#pragma unroll
-    for (int k = 0; k < KL; ++k) { tm[k] = T(0); acc[k] = T(0); }
-    if (live) load_row<KL>(a.tab_major + (size_t)major * KP + sub * KL, tm);
-    double llh = 0.0;
-
-    const uint4 *__restrict__ ep = a.entries + a.slice_off[slice] + slot;
-    const int steps = a.slice_steps[slice];
-    const T *__restrict__ tabm = a.tab_minor + sub * KL;
-
-    for (int p = 0; p < steps; ++p) {
-        const uint4 e = stream_load(ep + (size_t)p * CPW);
-        T b0[KL], b1[KL];
-        load_row<KL>(tabm + (size_t)e.x * KP, b0);
-        load_row<KL>(tabm + (size_t)e.z * KP, b1);
-        const T x0 = (T)__uint_as_float(e.y);
-        const T x1 = (T)__uint_as_float(e.w);
-        T s0 = T(0), s1 = T(0);
-#pragma unroll
-        for (int k = 0; k < KL; ++k) { s0 += tm[k] * b0[k]; s1 += tm[k] * b1[k]; }
-        s0 = group_sum<T, LPC>(s0);
-        s1 = group_sum<T, LPC>(s1);
-        if (MODE == MODE_PHI) {
-            const bool bad0 = x0 > T(0) && !(s0 >= Tiny<T>::v());
-            const bool bad1 = x1 > T(0) && !(s1 >= Tiny<T>::v());
-            const T w0 = (x0 > T(0) && !bad0) ? x0 / s0 : T(0);
-            const T w1 = (x1 > T(0) && !bad1) ? x1 / s1 : T(0);
-#pragma unroll
-            for (int k = 0; k < KL; ++k) acc[k] += w0 * b0[k] + w1 * b1[k];
-            if (__builtin_expect(bad0 || bad1, 0)) {
-                // log-domain fallback, the reference's own form (hpf_numba.py:98-112)
-#pragma unroll 1
-                for (int u = 0; u < 2; ++u) {
-                    const bool bad = u ? bad1 : bad0;
-                    if (!bad) continue;
-                    const unsigned idx = u ? e.z : e.x;
-                    const T x = u ? x1 : x0;
-                    T lr[KL];
-                    T lm[KL];
-                    load_row<KL>(a.log_major + (size_t)major * KP + sub * KL, lr);
-                    load_row<KL>(a.log_minor + (size_t)idx * KP + sub * KL, lm);
-                    T mx = -INFINITY;
-#pragma unroll
-                    for (int k = 0; k < KL; ++k) {
-                        lr[k] += lm[k];
-                        if (sub * KL + k < a.K) mx = lr[k] > mx ? lr[k] : mx;
-                    }
-                    mx = group_max<T, LPC>(mx);
-                    T ss = T(0);
-#pragma unroll
-                    for (int k = 0; k < KL; ++k) {
-                        lr[k] = (sub * KL + k < a.K) ? (T)exp((double)(lr[k] - mx)) : T(0);
-                        ss += lr[k];
-                    }
-                    ss = group_sum<T, LPC>(ss);
-#pragma unroll
-                    for (int k = 0; k < KL; ++k)
-                        if (sub * KL + k < a.K)
-                            atomicAdd(a.extra + (size_t)major * KP + sub * KL + k, x * lr[k] / ss);
-                    *a.extra_flag = 1;
-                }
-            }
-        } else {
-            if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
-            if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
-        }
-    }
-
-    if (MODE == MODE_PHI) {
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < KL; ++k) acc[k] *= tm[k];
-            const int nat = a.chunk_natid[(size_t)slice * CPW + slot];
-            store_row<KL>(a.partials + (size_t)nat * KP + sub * KL, acc);
-        }
-    } else {
-        if (sub != 0) llh = 0.0;
-        llh = wave_sum(llh);
-        if (lane == 0) a.wave_out[wave] = llh;
-    }
 }
 
 // ------------------------------------------------------- fused Gamma update + tables
@@ -400,70 +216,6 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const double *__restri
     out[i] = (T)acc;
 }
 
-// Device-side variant for matrices too large for a host draw: phi_k = e_k / sum e,
-// e_k ~ Exp(1) from a counter-based hash of (seed, cell, gene, k), so the cell sweep
-// and the gene sweep regenerate identical responsibilities.  One lane group per chunk,
-// same plan as the sweeps.  Not seed-compatible with NumPy (documented).
-__device__ __forceinline__ uint64_t mix64(uint64_t z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ double exp1_draw(uint64_t seed, uint64_t cell, uint64_t gene, unsigned k)
-{
-    uint64_t h = mix64(seed ^ mix64(cell * 0x100000001B3ull + gene) ^ ((uint64_t)k << 48));
-    double u = ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);  // (0,1)
-    return -log(u);
-}
-template <typename T, int KL, int LPC>
-__global__ __launch_bounds__(256) void random_phi_sweep_kernel(SweepArgs<T> a, uint64_t seed,
-                                                               int major_is_cell)
-{
-    constexpr int CPW = 64 / LPC;
-    constexpr int KP = KL * LPC;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int slice = a.wave_slice[wave];
-    if (slice < 0) return;
-    const int lane = threadIdx.x & 63;
-    const int slot = lane / LPC, sub = lane % LPC;
-    const int major = a.chunk_major[(size_t)slice * CPW + slot];
-    if (major < 0) return;  // whole lane group leaves together
-    double acc[KL];
-#pragma unroll
-    for (int k = 0; k < KL; ++k) acc[k] = 0.0;
-    const uint4 *__restrict__ ep = a.entries + a.slice_off[slice] + slot;
-    const int steps = a.slice_steps[slice];
-    for (int p = 0; p < steps; ++p) {
-        const uint4 e = ep[(size_t)p * CPW];
-#pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
-            const unsigned minor = u ? e.z : e.x;
-            const double x = (double)__uint_as_float(u ? e.w : e.y);
-            if (!(x > 0.0)) continue;
-            const uint64_t cell = major_is_cell ? (uint64_t)major : (uint64_t)minor;
-            const uint64_t gene = major_is_cell ? (uint64_t)minor : (uint64_t)major;
-            double d[KL];
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < KL; ++k) {
-                const int kk = sub * KL + k;
-                d[k] = kk < a.K ? exp1_draw(seed, cell, gene, (unsigned)kk) : 0.0;
-                s += d[k];
-            }
-            s = group_sum<double, LPC>(s);
-#pragma unroll
-            for (int k = 0; k < KL; ++k) acc[k] += x * d[k] / s;
-        }
-    }
-    const int nat = a.chunk_natid[(size_t)slice * CPW + slot];
-    T out[KL];
-#pragma unroll
-    for (int k = 0; k < KL; ++k) out[k] = (T)acc[k];
-    store_row<KL>(a.partials + (size_t)nat * KP + sub * KL, out);
-}
-
 // ------------------------------------------------------ stateless operator mirrors
 // Array-in / array-out counterparts of the reference's numba callables, in the
 // caller's COO order.  Used by schpf_amd.hpf_hip and by the parity tests.
@@ -606,64 +358,6 @@ __global__ __launch_bounds__(256) void gammaln_array_kernel(const double *__rest
 // never a zero-sized grid: every kernel bounds-checks, an empty problem launches one idle block
 static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 255) / 256) : 1u; }
 
-template <typename T, int KL, int LPC>
-static hipError_t launch_sweep_t(const SweepArgs<T> &a, int mode, int64_t n_waves, hipStream_t st)
-{
-    if (sizeof(T) == 4 && (KL % 4) != 0) return hipErrorInvalidValue;  // float rows are float4-granular
-    if (n_waves == 0) return hipSuccess;
-    dim3 grid((unsigned)(n_waves / 4)), block(256);
-    if (mode == MODE_PHI)
-        hipLaunchKernelGGL((sweep_kernel<T, KL, LPC, MODE_PHI>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((sweep_kernel<T, KL, LPC, MODE_LLH>), grid, block, 0, st, a);
-    return hipGetLastError();
-}
-template <typename T, int KL, int LPC>
-static hipError_t launch_random_t(const SweepArgs<T> &a, uint64_t seed, int major_is_cell, int64_t n_waves,
-                                  hipStream_t st)
-{
-    if (sizeof(T) == 4 && (KL % 4) != 0) return hipErrorInvalidValue;
-    if (n_waves == 0) return hipSuccess;
-    hipLaunchKernelGGL((random_phi_sweep_kernel<T, KL, LPC>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, st,
-                       a, seed, major_is_cell);
-    return hipGetLastError();
-}
-
-#define SCHPF_FOR_LPC(T, KL, LPC_VAR, CALL)                                   \
-    switch (LPC_VAR) {                                                        \
-    case 1: { constexpr int LPC = 1; return CALL; }                           \
-    case 2: { constexpr int LPC = 2; return CALL; }                           \
-    case 4: { constexpr int LPC = 4; return CALL; }                           \
-    case 8: { constexpr int LPC = 8; return CALL; }                           \
-    default: return hipErrorInvalidValue;                                     \
-    }
-#define SCHPF_DISPATCH(T, kl, lpc, CALLEXPR)                                                   \
-    switch (kl) {                                                                              \
-    case 2: { constexpr int KL = 2; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                      \
-    case 6: { constexpr int KL = 6; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                      \
-    case 10: { constexpr int KL = 10; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                    \
-    case 4: { constexpr int KL = 4; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                      \
-    case 8: { constexpr int KL = 8; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                      \
-    case 12: { constexpr int KL = 12; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                    \
-    case 16: { constexpr int KL = 16; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                    \
-    case 20: { constexpr int KL = 20; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                    \
-    case 24: { constexpr int KL = 24; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                    \
-    case 32: { constexpr int KL = 32; SCHPF_FOR_LPC(T, KL, lpc, CALLEXPR) }                    \
-    default: return hipErrorInvalidValue;                                                      \
-    }
-
-template <typename T>
-hipError_t launch_sweep(const SweepArgs<T> &a, int kl, int lpc, int mode, int64_t n_waves, hipStream_t st)
-{
-    SCHPF_DISPATCH(T, kl, lpc, (launch_sweep_t<T, KL, LPC>(a, mode, n_waves, st)))
-}
-template <typename T>
-hipError_t launch_random_phi(const SweepArgs<T> &a, int kl, int lpc, uint64_t seed, int major_is_cell,
-                             int64_t n_waves, hipStream_t st)
-{
-    SCHPF_DISPATCH(T, kl, lpc, (launch_random_t<T, KL, LPC>(a, seed, major_is_cell, n_waves, st)))
-}
-
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st)
 {
     const size_t lds = ((size_t)2 * a.rows_per_block * a.K + a.K) * sizeof(double);
@@ -782,9 +476,6 @@ hipError_t launch_gammaln_array(const double *x, int64_t n, double *out, hipStre
 
 // explicit instantiations for the two model dtypes
 #define SCHPF_INSTANTIATE(T)                                                                                   \
-    template hipError_t launch_sweep<T>(const SweepArgs<T> &, int, int, int, int64_t, hipStream_t);            \
-    template hipError_t launch_random_phi<T>(const SweepArgs<T> &, int, int, uint64_t, int, int64_t,           \
-                                             hipStream_t);                                                     \
     template hipError_t launch_gamma_update<T>(const UpdateArgs<T> &, int, int, hipStream_t);                  \
     template hipError_t launch_combine_partials<T>(const T *, const int *, int, int, int, T *, const int *,    \
                                                    T *, hipStream_t);                                          \

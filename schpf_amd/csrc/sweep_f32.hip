@@ -1,0 +1,6 @@
+// float32 instantiation of the sweep kernels (see sweep_impl.h)
+#include "sweep_impl.h"
+namespace schpf {
+template hipError_t launch_sweep<float>(const SweepArgs<float> &, int, int, int, int64_t, hipStream_t);
+template hipError_t launch_random_phi<float>(const SweepArgs<float> &, int, int, uint64_t, int, int64_t, hipStream_t);
+}  // namespace schpf

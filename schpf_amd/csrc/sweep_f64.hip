@@ -1,0 +1,6 @@
+// float64 instantiation of the sweep kernels (see sweep_impl.h)
+#include "sweep_impl.h"
+namespace schpf {
+template hipError_t launch_sweep<double>(const SweepArgs<double> &, int, int, int, int64_t, hipStream_t);
+template hipError_t launch_random_phi<double>(const SweepArgs<double> &, int, int, uint64_t, int, int64_t, hipStream_t);
+}  // namespace schpf
