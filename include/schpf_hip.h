@@ -168,6 +168,15 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                             int32_t *out_natid, int32_t *out_wave, int32_t *out_cptr,
                             int64_t stats[4]);
 
+/* Same for the tile plan (LDS-staged sweep): per stored nonzero the major/minor/val, the partial
+ * row (task * groups_per_block + group) it accumulates into and its task; pfirst/pcount[n_major];
+ * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task}. */
+int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                            int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
+                            int target_tasks, int32_t *out_major, int32_t *out_minor, float *out_val,
+                            int32_t *out_prow, int32_t *out_task, int32_t *out_pfirst,
+                            int32_t *out_pcount, int64_t stats[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,8 @@ SIGNATURES = {
     "schpf_plan_info": [_vp, _i64p],
     "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64p],
+    "schpf_debug_tile_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p],
 }
 STRING_FUNCS = ("schpf_last_error", "schpf_version")
 

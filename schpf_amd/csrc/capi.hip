@@ -67,6 +67,12 @@ struct DevBuf {
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
     ~DevBuf() { release(); }
     void release()
     {
@@ -100,6 +106,15 @@ struct PlanDev {
     schpf::SweepPlanHost host;  // entries cleared after upload; order/mptr/cptr kept
     DevBuf entries, slice_off, slice_steps, chunk_major, chunk_natid, wave_slice, cptr, partials;
     int64_t n_waves = 0, n_chunks = 0, entry_slots = 0;
+};
+
+struct TileDev {
+    schpf::TilePlanHost host;   // entries/steps cleared after upload; order/mptr kept
+    DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, task_wave_end, pfirst, pcount,
+        partials;
+    int64_t n_tasks = 0, entry_slots = 0, n_wave_out = 0;
+    int threads = 512;
+    size_t lds_bytes = 0;
 };
 
 struct Profiler {
@@ -163,19 +178,20 @@ template <typename T> struct Engine final : schpf_ctx {
     DevBuf xi_s, xi_r, th_s, th_r, eta_s, eta_r, be_s, be_r;
     // tables, stride KP, padding columns zero
     DevBuf th_exp, th_e, th_log, be_exp, be_e, be_log;
-    DevBuf extra_cell, extra_gene, flags;           // fallback accumulators + 2 int flags
     DevBuf exchange_buf;                            // [G*K + K] of T
     DevBuf dense_cell;                              // [N*K] of T (t = 0 only)
     DevBuf s_theta, s_beta, s_beta_next;            // double[K]
     DevBuf colpart_cell, colpart_gene;              // double[UPD_BLOCKS * K]
     DevBuf wave_out, scalars;                       // llh per wave; scalars[0]=llh sum
-    PlanDev cell, gene;                             // major = cell / major = gene
+    PlanDev cell, gene;                             // gather plans: major = cell / major = gene
+    TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
+    bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
     double gammaln_sum = 0.0;
     bool have_coo = false;
     bool dirty_theta = true, dirty_beta = true;
     int pending_init = 0;  // 0 none, 1 dense accumulators, 2 chunk partials
-    static constexpr int UPD_BLOCKS = 1024;
+    static constexpr int UPD_BLOCKS = 2048;
 
     Engine(int device_, void *stream_, int dtype_, int N_, int G_, int K_)
     {
@@ -189,9 +205,8 @@ template <typename T> struct Engine final : schpf_ctx {
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
         be_s.alloc((size_t)G * K * s); be_r.alloc((size_t)G * K * s);
-        for (DevBuf *b : {&th_exp, &th_e, &th_log, &extra_cell}) b->alloc((size_t)N * KP * s, true, stream);
-        for (DevBuf *b : {&be_exp, &be_e, &be_log, &extra_gene}) b->alloc((size_t)G * KP * s, true, stream);
-        flags.alloc(2 * sizeof(int), true, stream);
+        for (DevBuf *b : {&th_exp, &th_e, &th_log}) b->alloc((size_t)N * KP * s, true, stream);
+        for (DevBuf *b : {&be_exp, &be_e, &be_log}) b->alloc((size_t)G * KP * s, true, stream);
         exchange_buf.alloc(((size_t)G * K + K) * s, true, stream);
         for (DevBuf *b : {&s_theta, &s_beta, &s_beta_next}) b->alloc((size_t)K * sizeof(double), true, stream);
         colpart_cell.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
@@ -204,27 +219,37 @@ template <typename T> struct Engine final : schpf_ctx {
         if (own_stream) (void)hipStreamDestroy(stream);
     }
 
-    // Row layout of the gathered tables: KP = NV * LPC * VEC values (VEC = values per 16 B).
-    // One gather instruction makes a group's LPC lanes read LPC*16 contiguous bytes; the L1
-    // path is charged per 64-byte sector touched, so the cost model is
-    //   accesses per nonzero = NV * max(1, LPC/4)
-    // and the (LPC, NV) with the fewest accesses wins (ties: the earlier LPC in the list).
+    // Row layout of the tables the sweeps read: KP = NV * LPC * VEC values (VEC = values per 16 B);
+    // a group of LPC lanes shares one row, lane `sub` holding the 16-byte vectors q*LPC + sub.
+    //  * tile plan (LDS-staged): VALU work per nonzero has a fixed part (reciprocal, cross-lane
+    //    sum, addressing) that every lane of the group repeats, so rows are split over as FEW
+    //    lanes as the register budget allows: the smallest LPC with <= 112 row bytes per lane
+    //    (measured on C3: f64 K=20 -> LPC 2, f32 K=20 -> LPC 1; profiles/r01/explore*.log);
+    //  * gather plan (L2): the L1 path is charged per 64-byte sector touched, so the cost model
+    //    is accesses per nonzero = NV * max(1, LPC/4) and LPC = 4 usually wins.
     void choose_config()
     {
         if (K < 1 || K > 256) throw std::invalid_argument("nfactors must be in [1, 256]");
         const int vec = 16 / (int)sizeof(T);
         const int nvec = (K + vec - 1) / vec;
-        static const int nv_ok[] = {1, 2, 3, 4, 5, 6, 8};
-        static const int lpc_order[] = {4, 8, 2, 16, 1};
+        static const int nv_ok[] = {1, 2, 3, 4, 5, 6, 7, 8, 10};
+        const char *pk = getenv("SCHPF_PLAN");
+        want_tile = (size_t)nvec * 16 <= 1024;          // at least ~150 rows per 152 KiB window
+        if (pk && !strcmp(pk, "gather")) want_tile = false;
+        if (pk && !strcmp(pk, "tile")) want_tile = true;
         const int force_lpc = env_int("SCHPF_LPC", 0);
         int best_lpc = 0, best_nv = 0, best_cost = 1 << 30;
-        for (int lpc : lpc_order) {
+        static const int order_tile[] = {1, 2, 4, 8, 16};
+        static const int order_gather[] = {4, 8, 2, 16, 1};
+        for (int lpc : (want_tile ? order_tile : order_gather)) {
             if (force_lpc && lpc != force_lpc) continue;
             const int need = (nvec + lpc - 1) / lpc;
             int nv = 0;
             for (int v : nv_ok) if (v >= need) { nv = v; break; }
             if (!nv) continue;
-            const int cost = nv * std::max(1, lpc / 4);
+            int cost;
+            if (want_tile) cost = (nv * 16 <= 112 || force_lpc) ? 0 : 1 << 20;   // first that fits
+            else cost = nv * std::max(1, lpc / 4);
             if (cost < best_cost) { best_cost = cost; best_lpc = lpc; best_nv = nv; }
         }
         if (!best_lpc) throw std::invalid_argument("SCHPF_LPC must be one of 1,2,4,8,16 and fit nfactors");
@@ -267,6 +292,61 @@ template <typename T> struct Engine final : schpf_ctx {
         std::vector<int32_t>().swap(h.slice_steps);
     }
 
+    void build_tile(TileDev &td, int64_t nnz_, const int32_t *major, const int32_t *minor, const float *val,
+                    int n_major, int n_minor, int win_rows, int wpb, int target_tasks)
+    {
+        schpf::build_tile_plan(nnz_, major, minor, val, n_major, n_minor, LPC, wpb, win_rows, target_tasks, true,
+                               td.host);
+        auto &h = td.host;
+        td.n_tasks = h.n_tasks;
+        td.threads = 64 * wpb;
+        td.lds_bytes = (size_t)win_rows * KP * sizeof(T);
+        td.entry_slots = (int64_t)h.entries.size() / 2;
+        td.n_wave_out = h.n_tasks * wpb;
+        upload(td.entries, h.entries, stream);
+        upload(td.steps, h.steps, stream);
+        upload(td.block_rows, h.block_rows, stream);
+        upload(td.task_block, h.task_block, stream);
+        upload(td.task_w0, h.task_w0, stream);
+        upload(td.task_w1, h.task_w1, stream);
+        upload(td.task_wave_off, h.task_wave_off, stream);
+        upload(td.task_wave_end, h.task_wave_end, stream);
+        upload(td.pfirst, h.pfirst, stream);
+        upload(td.pcount, h.pcount, stream);
+        td.partials.alloc((size_t)std::max<int64_t>(h.n_partial_rows, 1) * KP * sizeof(T), true, stream);
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<uint32_t>().swap(h.entries);
+        std::vector<uint16_t>().swap(h.steps);
+        std::vector<int64_t>().swap(h.task_wave_off);
+        std::vector<int64_t>().swap(h.task_wave_end);
+    }
+
+    // Workgroup shape of the tile sweep.  Big problems: one 1024-thread workgroup per CU with a
+    // 152 KiB window (fewest stagings, longest row segments => least sliced-ELL padding).  When
+    // that leaves the 256 CUs short of tasks the workgroup is halved (64 KiB windows, two
+    // workgroups per CU) until there are enough (block, window) pairs.
+    void build_tile_auto(TileDev &td, const int32_t *major, const int32_t *minor, const float *val, int n_major,
+                         int n_minor)
+    {
+        int wpb = env_int("SCHPF_WPB", 0), lds_kb = env_int("SCHPF_LDS_KB", 0);
+        const size_t row_bytes = (size_t)KP * sizeof(T);
+        if (!wpb) {
+            wpb = 16;
+            for (;;) {
+                const int kb = lds_kb ? lds_kb : (wpb >= 12 ? 152 : 64);
+                const int64_t wr = std::max<int64_t>(1, (int64_t)kb * 1024 / (int64_t)row_bytes);
+                const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
+                const int64_t windows = ((int64_t)n_minor + wr - 1) / wr;
+                if (blocks * windows >= 768 || wpb <= 2) break;
+                wpb /= 2;
+            }
+        }
+        if (!lds_kb) lds_kb = wpb >= 12 ? 152 : 64;
+        const int win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
+        const int tasks = env_int("SCHPF_TASKS", wpb >= 12 ? 1024 : 2048);
+        build_tile(td, nnz, major, minor, val, n_major, n_minor, win_rows, wpb, tasks);
+    }
+
     void upload_coo(int64_t nnz_, const int32_t *row, const int32_t *col, const void *val, int kind) override
     {
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
@@ -299,11 +379,21 @@ template <typename T> struct Engine final : schpf_ctx {
         }
         if (chunk < 2) chunk = 2;
         chunk &= ~1;
-        const int wc = pick_windows((size_t)G * KP * sizeof(T), "SCHPF_WINDOWS_CELL");
-        const int wg = pick_windows((size_t)N * KP * sizeof(T), "SCHPF_WINDOWS_GENE");
-        build_plan(cell, nnz, row, col, v.data(), N, G, wc, chunk);
-        build_plan(gene, nnz, col, row, v.data(), G, N, wg, chunk);
-        wave_out.alloc((size_t)std::max<int64_t>(cell.n_waves, 1) * sizeof(double), true, stream);
+        use_tile = want_tile;
+        cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
+        int64_t n_out;
+        if (use_tile) {
+            build_tile_auto(tcell, row, col, v.data(), N, G);
+            build_tile_auto(tgene, col, row, v.data(), G, N);
+            n_out = tcell.n_wave_out;
+        } else {
+            const int wc = pick_windows((size_t)G * KP * sizeof(T), "SCHPF_WINDOWS_CELL");
+            const int wg = pick_windows((size_t)N * KP * sizeof(T), "SCHPF_WINDOWS_GENE");
+            build_plan(cell, nnz, row, col, v.data(), N, G, wc, chunk);
+            build_plan(gene, nnz, col, row, v.data(), G, N, wg, chunk);
+            n_out = cell.n_waves;
+        }
+        wave_out.alloc((size_t)std::max<int64_t>(n_out, 1) * sizeof(double), true, stream);
 
         // constant term of the loss: sum lgamma(x + 1)   (hpf_numba.py:49-50)
         DevBuf dv, part;
@@ -399,7 +489,7 @@ template <typename T> struct Engine final : schpf_ctx {
     }
 
     schpf::SweepArgs<T> sweep_args(PlanDev &pd, const DevBuf &tab_major, const DevBuf &tab_minor,
-                                   const DevBuf &log_major, const DevBuf &log_minor, DevBuf &extra, int flag_ix)
+                                   const DevBuf &log_major, const DevBuf &log_minor)
     {
         schpf::SweepArgs<T> a{};
         a.entries = pd.entries.as<uint4>();
@@ -413,11 +503,70 @@ template <typename T> struct Engine final : schpf_ctx {
         a.log_major = log_major.as<T>();
         a.log_minor = log_minor.as<T>();
         a.partials = pd.partials.as<T>();
-        a.extra = extra.as<T>();
-        a.extra_flag = flags.as<int>() + flag_ix;
         a.wave_out = wave_out.as<double>();
         a.K = K;
         return a;
+    }
+
+    schpf::TileArgs<T> tile_args(TileDev &td, const DevBuf &tab_major, const DevBuf &tab_minor,
+                                 const DevBuf &log_major, const DevBuf &log_minor, int n_minor)
+    {
+        schpf::TileArgs<T> a{};
+        a.entries = td.entries.as<uint4>();
+        a.steps = td.steps.as<uint16_t>();
+        a.block_rows = td.block_rows.as<int>();
+        a.task_block = td.task_block.as<int>();
+        a.task_w0 = td.task_w0.as<int>();
+        a.task_w1 = td.task_w1.as<int>();
+        a.task_wave_off = td.task_wave_off.as<int64_t>();
+        a.task_wave_end = td.task_wave_end.as<int64_t>();
+        a.tab_major = tab_major.as<T>();
+        a.tab_minor = tab_minor.as<T>();
+        a.log_major = log_major.as<T>();
+        a.log_minor = log_minor.as<T>();
+        a.partials = td.partials.as<T>();
+        a.wave_out = wave_out.as<double>();
+        a.K = K; a.n_minor = n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
+        a.wpb = td.host.wpb;
+        return a;
+    }
+
+    // one sweep of either plan kind.  side 0: major = cell, side 1: major = gene.
+    void run_sweep(int side, int mode, uint64_t seed = 0)
+    {
+        const bool cellside = side == 0;
+        const DevBuf &tmaj = mode == schpf::MODE_LLH ? (cellside ? th_e : be_e) : (cellside ? th_exp : be_exp);
+        const DevBuf &tmin = mode == schpf::MODE_LLH ? (cellside ? be_e : th_e) : (cellside ? be_exp : th_exp);
+        const DevBuf &lmaj = cellside ? th_log : be_log;
+        const DevBuf &lmin = cellside ? be_log : th_log;
+        if (use_tile) {
+            TileDev &td = cellside ? tcell : tgene;
+            auto a = tile_args(td, tmaj, tmin, lmaj, lmin, cellside ? G : N);
+            a.seed = seed; a.major_is_cell = cellside ? 1 : 0;
+            HIPCHK(schpf::launch_tile_sweep<T>(a, NV, LPC, mode, td.n_tasks, td.threads, td.lds_bytes, stream));
+        } else {
+            PlanDev &pd = cellside ? cell : gene;
+            auto a = sweep_args(pd, tmaj, tmin, lmaj, lmin);
+            if (mode == schpf::MODE_RANDOM)
+                HIPCHK(schpf::launch_random_phi<T>(a, NV, LPC, seed, cellside ? 1 : 0, pd.n_waves, stream));
+            else
+                HIPCHK(schpf::launch_sweep<T>(a, NV, LPC, mode, pd.n_waves, stream));
+        }
+    }
+
+    // where the update kernel finds a side's accumulated chunk/task partials
+    void partial_source(int side, schpf::UpdateArgs<T> &u, int &src)
+    {
+        if (use_tile) {
+            TileDev &td = side == 0 ? tcell : tgene;
+            src = schpf::SRC_STRIDED;
+            u.partials = td.partials.as<T>(); u.pfirst = td.pfirst.as<int>(); u.pcount = td.pcount.as<int>();
+            u.pstride = td.host.pstride;
+        } else {
+            PlanDev &pd = side == 0 ? cell : gene;
+            src = schpf::SRC_PARTIALS;
+            u.partials = pd.partials.as<T>(); u.cptr = pd.cptr.as<int>();
+        }
     }
 
     void need_coo() const
@@ -432,13 +581,13 @@ template <typename T> struct Engine final : schpf_ctx {
         dx.alloc((size_t)nnz * K * sizeof(double));
         HIPCHK(hipMemcpyAsync(dx.p, xphi, (size_t)nnz * K * sizeof(double), hipMemcpyHostToDevice, stream));
         dense_cell.alloc((size_t)N * K * sizeof(T));
-        upload(ord, cell.host.order, stream);
-        upload(mp, cell.host.mptr, stream);
+        upload(ord, use_tile ? tcell.host.order : cell.host.order, stream);
+        upload(mp, use_tile ? tcell.host.mptr : cell.host.mptr, stream);
         HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord.as<int>(), mp.as<int64_t>(), N, K,
                                             dense_cell.as<T>(), stream));
         HIPCHK(hipStreamSynchronize(stream));
-        upload(ord, gene.host.order, stream);
-        upload(mp, gene.host.mptr, stream);
+        upload(ord, use_tile ? tgene.host.order : gene.host.order, stream);
+        upload(mp, use_tile ? tgene.host.mptr : gene.host.mptr, stream);
         HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord.as<int>(), mp.as<int64_t>(), G, K,
                                             exchange_buf.as<T>(), stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -448,10 +597,8 @@ template <typename T> struct Engine final : schpf_ctx {
     void init_phi_device(uint64_t seed) override
     {
         need_coo();
-        auto ac = sweep_args(cell, th_exp, be_exp, th_log, be_log, extra_cell, 0);
-        HIPCHK(schpf::launch_random_phi<T>(ac, NV, LPC, seed, 1, cell.n_waves, stream));
-        auto ag = sweep_args(gene, be_exp, th_exp, be_log, th_log, extra_gene, 1);
-        HIPCHK(schpf::launch_random_phi<T>(ag, NV, LPC, seed, 0, gene.n_waves, stream));
+        run_sweep(0, schpf::MODE_RANDOM, seed);
+        run_sweep(1, schpf::MODE_RANDOM, seed);
         pending_init = 2;
     }
 
@@ -464,22 +611,24 @@ template <typename T> struct Engine final : schpf_ctx {
         if (pending_init == 0) {
             {
                 ScopedTimer tm(prof, stream, 0);
-                auto ac = sweep_args(cell, th_exp, be_exp, th_log, be_log, extra_cell, 0);
-                HIPCHK(schpf::launch_sweep<T>(ac, NV, LPC, schpf::MODE_PHI, cell.n_waves, stream));
+                run_sweep(0, schpf::MODE_PHI);
                 tm.stop();
             }
             if (!freeze) {
                 ScopedTimer tm(prof, stream, 1);
-                auto ag = sweep_args(gene, be_exp, th_exp, be_log, th_log, extra_gene, 1);
-                HIPCHK(schpf::launch_sweep<T>(ag, NV, LPC, schpf::MODE_PHI, gene.n_waves, stream));
+                run_sweep(1, schpf::MODE_PHI);
                 tm.stop();
             }
         }
         if (sharded && !freeze && pending_init != 1) {
-            // fixed-order reduction of this rank's gene-side chunk partials into the exchange buffer
-            HIPCHK(schpf::launch_combine_partials<T>(gene.partials.as<T>(), gene.cptr.as<int>(), G, K, KP,
-                                                     extra_gene.as<T>(), flags.as<int>() + 1,
-                                                     exchange_buf.as<T>(), stream));
+            // fixed-order reduction of this rank's gene-side partials into the exchange buffer
+            if (use_tile)
+                HIPCHK(schpf::launch_combine_strided<T>(tgene.partials.as<T>(), tgene.pfirst.as<int>(),
+                                                        tgene.pcount.as<int>(), tgene.host.pstride, G, K, KP,
+                                                        exchange_buf.as<T>(), stream));
+            else
+                HIPCHK(schpf::launch_combine_partials<T>(gene.partials.as<T>(), gene.cptr.as<int>(), G, K, KP,
+                                                         exchange_buf.as<T>(), stream));
         }
     }
 
@@ -503,11 +652,7 @@ template <typename T> struct Engine final : schpf_ctx {
             u.n = G; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
             int src;
             if (sharded || pending_init == 1) { src = schpf::SRC_DENSE; u.dense = exchange_buf.as<T>(); }
-            else {
-                src = schpf::SRC_PARTIALS;
-                u.partials = gene.partials.as<T>(); u.cptr = gene.cptr.as<int>();
-                u.extra = extra_gene.as<T>(); u.extra_flag = flags.as<int>() + 1;
-            }
+            else partial_source(1, u, src);
             u.prior_shape = c;
             u.cap_shape = eta_s.as<T>(); u.cap_rate = eta_r.as<T>();
             u.s_other = s_theta.as<double>();
@@ -525,11 +670,7 @@ template <typename T> struct Engine final : schpf_ctx {
             u.n = N; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
             int src;
             if (pending_init == 1) { src = schpf::SRC_DENSE; u.dense = dense_cell.as<T>(); }
-            else {
-                src = schpf::SRC_PARTIALS;
-                u.partials = cell.partials.as<T>(); u.cptr = cell.cptr.as<int>();
-                u.extra = extra_cell.as<T>(); u.extra_flag = flags.as<int>() + 0;
-            }
+            else partial_source(0, u, src);
             u.prior_shape = a;
             u.cap_shape = xi_s.as<T>(); u.cap_rate = xi_r.as<T>();
             // theta.rate uses the beta just updated (scHPF_.py:711-713) unless the updates are
@@ -545,8 +686,6 @@ template <typename T> struct Engine final : schpf_ctx {
                                                exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
         }
         if (!freeze) std::swap(s_beta.p, s_beta_next.p);
-        // both consumers of the fallback accumulators have run: clear their flags
-        HIPCHK(hipMemsetAsync(flags.p, 0, 2 * sizeof(int), stream));
         if (pending_init == 1) dense_cell.release();
         pending_init = 0;
         tm.stop();
@@ -559,9 +698,9 @@ template <typename T> struct Engine final : schpf_ctx {
         need_coo();
         refresh_tables();
         ScopedTimer tm(prof, stream, 2);
-        auto ac = sweep_args(cell, th_e, be_e, th_log, be_log, extra_cell, 0);
-        HIPCHK(schpf::launch_sweep<T>(ac, NV, LPC, schpf::MODE_LLH, cell.n_waves, stream));
-        HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(), cell.n_waves, scalars.as<double>(), stream));
+        run_sweep(0, schpf::MODE_LLH);
+        HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(), use_tile ? tcell.n_wave_out : cell.n_waves,
+                                         scalars.as<double>(), stream));
         tm.stop();
         double h = 0.0;
         HIPCHK(hipMemcpyAsync(&h, scalars.p, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -574,11 +713,19 @@ template <typename T> struct Engine final : schpf_ctx {
     void plan_info(int64_t info[12]) override
     {
         info[0] = KP; info[1] = KL; info[2] = LPC;
-        info[3] = cell.host.chunk_len;
-        info[4] = cell.host.n_windows; info[5] = gene.host.n_windows;
-        info[6] = cell.n_chunks; info[7] = gene.n_chunks;
-        info[8] = cell.n_waves; info[9] = gene.n_waves;
-        info[10] = cell.entry_slots; info[11] = gene.entry_slots;
+        if (use_tile) {
+            info[3] = -tcell.host.win_rows;            // negative: tile plan, rows per LDS window
+            info[4] = tcell.host.n_windows; info[5] = tgene.host.n_windows;
+            info[6] = tcell.host.n_partial_rows; info[7] = tgene.host.n_partial_rows;
+            info[8] = tcell.n_tasks; info[9] = tgene.n_tasks;
+            info[10] = tcell.entry_slots; info[11] = tgene.entry_slots;
+        } else {
+            info[3] = cell.host.chunk_len;
+            info[4] = cell.host.n_windows; info[5] = gene.host.n_windows;
+            info[6] = cell.n_chunks; info[7] = gene.n_chunks;
+            info[8] = cell.n_waves; info[9] = gene.n_waves;
+            info[10] = cell.entry_slots; info[11] = gene.entry_slots;
+        }
     }
 };
 
@@ -898,6 +1045,52 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         for (int m = 0; m <= n_major; ++m) out_cptr[m] = P.cptr[(size_t)m];
         stats[0] = P.n_chunks; stats[1] = P.n_slices; stats[2] = P.n_waves;
         stats[3] = (int64_t)P.entries.size() / 2;
+    });
+}
+
+
+int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                            int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
+                            int target_tasks, int32_t *out_major, int32_t *out_minor, float *out_val,
+                            int32_t *out_prow, int32_t *out_task, int32_t *out_pfirst, int32_t *out_pcount,
+                            int64_t stats[6])
+{
+    return guarded([&] {
+        schpf::TilePlanHost P;
+        schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, lpc, waves_per_block, win_rows,
+                               target_tasks, false, P);
+        const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
+        int64_t n = 0;
+        for (int64_t t = 0; t < P.n_tasks; ++t) {
+            const int b = P.task_block[(size_t)t];
+            for (int v = 0; v < wpb; ++v) {
+                int64_t off = P.task_wave_off[(size_t)t * wpb + v];
+                for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
+                    const int steps = P.steps[((size_t)b * wpb + v) * W + w];
+                    for (int p = 0; p < steps; ++p)
+                        for (int grp = 0; grp < gpw; ++grp)
+                            for (int u = 0; u < 2; ++u) {
+                                const uint32_t *e = P.entries.data() + ((size_t)off + (size_t)p * gpw + grp) * 4 + (size_t)u * 2;
+                                float f;
+                                std::memcpy(&f, &e[1], 4);
+                                if (f == 0.0f) continue;
+                                if (n >= nnz) throw std::logic_error("tile plan stores more nonzeros than given");
+                                const int g = v * gpw + grp;
+                                out_major[n] = P.block_rows[(size_t)b * gpb + g];
+                                out_minor[n] = (int32_t)(w * P.win_rows + (int)e[0]);
+                                out_val[n] = f;
+                                out_prow[n] = (int32_t)(t * gpb + g);
+                                out_task[n] = (int32_t)t;
+                                ++n;
+                            }
+                    off += (int64_t)steps * gpw;
+                }
+            }
+        }
+        if (n != nnz) throw std::logic_error("tile plan lost nonzeros");
+        for (int m = 0; m < n_major; ++m) { out_pfirst[m] = P.pfirst[(size_t)m]; out_pcount[m] = P.pcount[(size_t)m]; }
+        stats[0] = P.n_tasks; stats[1] = P.n_blocks; stats[2] = P.n_windows; stats[3] = P.pstride;
+        stats[4] = (int64_t)P.entries.size() / 2; stats[5] = P.windows_per_task;
     });
 }
 

@@ -5,7 +5,8 @@
 
 namespace schpf {
 
-enum { MODE_PHI = 0, MODE_LLH = 1 };
+enum { MODE_PHI = 0, MODE_LLH = 1, MODE_RANDOM = 2 };
+enum { SRC_STRIDED = 3 };
 enum { SRC_NONE = 0, SRC_PARTIALS = 1, SRC_DENSE = 2 };
 
 template <typename T> struct SweepArgs {
@@ -20,10 +21,26 @@ template <typename T> struct SweepArgs {
     const T *log_major;         // [n_major, KP] E[log x] (fallback only)
     const T *log_minor;         // [n_minor, KP]
     T *partials;                // [n_chunks, KP]
-    T *extra;                   // [n_major, KP] fallback accumulator (zero unless flagged)
-    int *extra_flag;
     double *wave_out;           // [n_waves] (LLH)
     int K;
+};
+
+// LDS-staged sweep over a tile plan (plan.h, TilePlanHost)
+template <typename T> struct TileArgs {
+    const uint4 *entries;          // {local0, val0, local1, val1}
+    const uint16_t *steps;         // [(block * wpb + wave) * n_windows + window]
+    const int *block_rows;         // [n_blocks * gpb]
+    const int *task_block, *task_w0, *task_w1;
+    const int64_t *task_wave_off;  // [task * wpb + wave] first uint4 of the wave's entries in the task
+    const int64_t *task_wave_end;  // [task * wpb + wave] one past its last
+    const T *tab_major;            // [n_major, KP]
+    const T *tab_minor;            // [n_minor, KP]  (staged window by window)
+    const T *log_major, *log_minor;
+    T *partials;                   // [n_tasks * gpb, KP]
+    double *wave_out;              // [n_tasks * wpb] (LLH)
+    int K, n_minor, n_windows, win_rows, wpb;
+    uint64_t seed;                 // MODE_RANDOM
+    int major_is_cell;
 };
 
 template <typename T> struct UpdateArgs {
@@ -31,8 +48,8 @@ template <typename T> struct UpdateArgs {
     const T *partials;          // SRC_PARTIALS: [n_chunks, KP]
     const int *cptr;            //               [n + 1]
     const T *dense;             // SRC_DENSE:    [n, K]
-    T *extra;                   // [n, KP] or null
-    const int *extra_flag;
+    const int *pfirst, *pcount; // SRC_STRIDED:  partial rows pfirst[row] + j * pstride, j < pcount[row]
+    int64_t pstride;
     double prior_shape;         // a or c
     const T *cap_shape;         // xi / eta shape [n]
     const T *cap_rate;          // xi / eta rate BEFORE this update [n]
@@ -49,12 +66,18 @@ hipError_t launch_sweep(const SweepArgs<T> &a, int nv, int lpc, int mode, int64_
 template <typename T>
 hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t seed, int major_is_cell,
                              int64_t n_waves, hipStream_t st);
+template <typename T>
+hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int64_t n_tasks, int threads,
+                             size_t lds_bytes, hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);
 template <typename T>
-hipError_t launch_combine_partials(const T *partials, const int *cptr, int n, int K, int KP, T *extra,
-                                   const int *extra_flag, T *out, hipStream_t st);
+hipError_t launch_combine_partials(const T *partials, const int *cptr, int n, int K, int KP, T *out,
+                                   hipStream_t st);
+template <typename T>
+hipError_t launch_combine_strided(const T *partials, const int *pfirst, const int *pcount, int64_t pstride, int n,
+                                  int K, int KP, T *out, hipStream_t st);
 hipError_t launch_sum_doubles(const double *v, int64_t n, double *out, hipStream_t st);
 hipError_t launch_gammaln_sum(const float *x, int64_t n, double *block_out, int nblocks, hipStream_t st);
 template <typename T>

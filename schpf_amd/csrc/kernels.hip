@@ -17,15 +17,18 @@ namespace schpf {
 // ------------------------------------------------------------------ special functions
 // psi(x), x > 0: upward recurrence to x >= 10 then the Bernoulli asymptotic series
 // (Cephes psi).  Replaces the SciPy C psi the reference binds (hpf_numba.py:16-18).
-// Absolute error < 4e-16 on [1e-4, 1e6] against SciPy (tests/test_special_gpu.py).
+// Within 4e-15 (relative or absolute) of SciPy on [1e-4, 1e6] (tests/test_ops_gpu.py).
 __device__ __forceinline__ double dev_digamma(double x)
 {
-    double w = 0.0;
+    // sum_{j<n} 1/(x+j) accumulated as one fraction num/den: one division instead of up to ten
+    double num = 0.0, den = 1.0;
     while (x < 10.0) {
-        w += 1.0 / x;
+        num = fma(num, x, den);
+        den *= x;
         x += 1.0;
     }
-    const double z = 1.0 / (x * x);
+    const double r = 1.0 / x;
+    const double z = r * r;
     double p = 8.33333333333333333333E-2;
     p = p * z - 2.10927960927960927961E-2;
     p = p * z + 7.57575757575757575758E-3;
@@ -33,7 +36,22 @@ __device__ __forceinline__ double dev_digamma(double x)
     p = p * z + 3.96825396825396825397E-3;
     p = p * z - 8.33333333333333333333E-3;
     p = p * z + 8.33333333333333333333E-2;
-    return log(x) - 0.5 / x - z * p - w;
+    return log(x) - 0.5 * r - z * p - num / den;
+}
+
+// Fixed-order sum of n values `stride` apart, four loads in flight (the partial rows of one
+// major row live far apart in HBM/L2; a rolled loop would pay one memory latency per term).
+template <typename T> __device__ __forceinline__ double sum_strided(const T *__restrict__ p, int n, size_t stride)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= n; c += 4) {
+        const T v0 = p[0], v1 = p[stride], v2 = p[2 * stride], v3 = p[3 * stride];
+        s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        p += 4 * stride;
+    }
+    for (; c < n; ++c, p += stride) s0 += (double)*p;
+    return (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------- fused Gamma update + tables
@@ -58,7 +76,6 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
     const bool lane_on = r < rb;
     if (t < K) sC[t] = 0.0;
     const int groups = (a.n + rb - 1) / rb;
-    const bool use_extra = (SRC == SRC_PARTIALS || SRC == SRC_DENSE) && a.extra_flag && *a.extra_flag;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int row = grp * rb + r;
         const bool on = lane_on && row < a.n;
@@ -71,14 +88,13 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
             } else {
                 double acc = 0.0;
                 if (SRC == SRC_PARTIALS) {
-                    const int c0 = a.cptr[row], c1 = a.cptr[row + 1];
-                    for (int c = c0; c < c1; ++c) acc += (double)a.partials[(size_t)c * KP + k];
+                    acc = sum_strided(a.partials + (size_t)a.cptr[row] * KP + k, a.cptr[row + 1] - a.cptr[row],
+                                      (size_t)KP);
+                } else if (SRC == SRC_STRIDED) {
+                    acc = sum_strided(a.partials + (size_t)a.pfirst[row] * KP + k, a.pcount[row],
+                                      (size_t)a.pstride * KP);
                 } else {
                     acc = (double)a.dense[(size_t)row * K + k];
-                }
-                if (use_extra) {
-                    acc += (double)a.extra[(size_t)row * KP + k];
-                    a.extra[(size_t)row * KP + k] = T(0);  // self-cleaning
                 }
                 shape = a.prior_shape + acc;
                 rate = (double)a.cap_shape[row] / (double)a.cap_rate[row] + a.s_other[k];
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
                 rate = (double)(T)rate;
             }
             E = shape / rate;
-            L = dev_digamma(shape) - log(rate);
+            L = dev_digamma(shape) - log(rate);   // psi in double whatever T is (hpf_numba.py:16-18)
             a.tab_e[(size_t)row * KP + k] = (T)E;
             a.tab_log[(size_t)row * KP + k] = (T)L;
             E = (double)(T)E;
@@ -128,8 +144,17 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double *__rest
     const int lanes = 256 / K;          // partial accumulators per factor
     const int k = t % K, j = t / K;
     double s = 0.0;
-    if (j < lanes)
-        for (int b = j; b < nblocks; b += lanes) s += part[(size_t)b * K + k];
+    if (j < lanes) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = j;
+        for (; b + 3 * lanes < nblocks; b += 4 * lanes) {     // four loads in flight, fixed order
+            const double v0 = part[(size_t)b * K + k], v1 = part[(size_t)(b + lanes) * K + k];
+            const double v2 = part[(size_t)(b + 2 * lanes) * K + k], v3 = part[(size_t)(b + 3 * lanes) * K + k];
+            s += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; b < nblocks; b += lanes) s += part[(size_t)b * K + k];
+        s = (s + s1) + (s2 + s3);
+    }
     red[t] = s;
     __syncthreads();
     if (t < K) {
@@ -148,20 +173,24 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double *__rest
 template <typename T>
 __global__ __launch_bounds__(256) void combine_partials_kernel(const T *__restrict__ partials,
                                                                const int *__restrict__ cptr, int n, int K,
-                                                               int KP, T *__restrict__ extra,
-                                                               const int *__restrict__ extra_flag,
-                                                               T *__restrict__ out)
+                                                               int KP, T *__restrict__ out)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)n * K) return;
     const int row = (int)(i / K), k = (int)(i - (size_t)row * K);
-    double acc = 0.0;
-    for (int c = cptr[row]; c < cptr[row + 1]; ++c) acc += (double)partials[(size_t)c * KP + k];
-    if (extra_flag && *extra_flag) {
-        acc += (double)extra[(size_t)row * KP + k];
-        extra[(size_t)row * KP + k] = T(0);
-    }
-    out[i] = (T)acc;
+    out[i] = (T)sum_strided(partials + (size_t)cptr[row] * KP + k, cptr[row + 1] - cptr[row], (size_t)KP);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void combine_strided_kernel(const T *__restrict__ partials,
+                                                              const int *__restrict__ pfirst,
+                                                              const int *__restrict__ pcount, int64_t pstride,
+                                                              int n, int K, int KP, T *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n * K) return;
+    const int row = (int)(i / K), k = (int)(i - (size_t)row * K);
+    out[i] = (T)sum_strided(partials + (size_t)pfirst[row] * KP + k, pcount[row], (size_t)pstride * KP);
 }
 
 // sum of n doubles -> out[0]; single block, fixed order.
@@ -169,9 +198,14 @@ __global__ __launch_bounds__(256) void sum_doubles_kernel(const double *__restri
                                                           double *__restrict__ out)
 {
     __shared__ double red[256];
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
-    red[threadIdx.x] = s;
+    double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) {
+        const double v0 = v[i], v1 = v[i + 256], v2 = v[i + 512], v3 = v[i + 768];
+        s += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = (s + s1) + (s2 + s3);
     __syncthreads();
     for (int m = 128; m >= 1; m >>= 1) {
         if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
@@ -364,6 +398,7 @@ template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int
     dim3 grid((unsigned)nblocks), block(256);
     if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE>), grid, block, lds, st, a);
     else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS>), grid, block, lds, st, a);
+    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE>), grid, block, lds, st, a);
     return hipGetLastError();
 }
@@ -377,11 +412,20 @@ hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *
 }
 
 template <typename T>
-hipError_t launch_combine_partials(const T *partials, const int *cptr, int n, int K, int KP, T *extra,
-                                   const int *extra_flag, T *out, hipStream_t st)
+hipError_t launch_combine_partials(const T *partials, const int *cptr, int n, int K, int KP, T *out,
+                                   hipStream_t st)
 {
     hipLaunchKernelGGL((combine_partials_kernel<T>), dim3(blocks_for((int64_t)n * K)), dim3(256), 0, st,
-                       partials, cptr, n, K, KP, extra, extra_flag, out);
+                       partials, cptr, n, K, KP, out);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_combine_strided(const T *partials, const int *pfirst, const int *pcount, int64_t pstride, int n,
+                                  int K, int KP, T *out, hipStream_t st)
+{
+    hipLaunchKernelGGL((combine_strided_kernel<T>), dim3(blocks_for((int64_t)n * K)), dim3(256), 0, st,
+                       partials, pfirst, pcount, pstride, n, K, KP, out);
     return hipGetLastError();
 }
 
@@ -477,8 +521,9 @@ hipError_t launch_gammaln_array(const double *x, int64_t n, double *out, hipStre
 // explicit instantiations for the two model dtypes
 #define SCHPF_INSTANTIATE(T)                                                                                   \
     template hipError_t launch_gamma_update<T>(const UpdateArgs<T> &, int, int, hipStream_t);                  \
-    template hipError_t launch_combine_partials<T>(const T *, const int *, int, int, int, T *, const int *,    \
-                                                   T *, hipStream_t);                                          \
+    template hipError_t launch_combine_partials<T>(const T *, const int *, int, int, int, T *, hipStream_t);   \
+    template hipError_t launch_combine_strided<T>(const T *, const int *, const int *, int64_t, int, int, int,  \
+                                                  T *, hipStream_t);                                           \
     template hipError_t launch_segment_sum<T>(const double *, const int *, const int64_t *, int, int, T *,     \
                                               hipStream_t);                                                    \
     template hipError_t launch_elog<T>(const T *, const T *, int64_t, T *, hipStream_t);                       \

@@ -19,6 +19,24 @@ void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vect
     for (int64_t i = 0; i < n; ++i) order[(size_t)cur[key[i]]++] = (int32_t)i;
 }
 
+void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
+                         std::vector<int32_t> &order, std::vector<int64_t> &mptr)
+{
+    // minor first, then stable by major
+    std::vector<int32_t> by_minor;
+    std::vector<int64_t> tmp_ptr;
+    counting_sort_positions(nnz, minor, n_minor, by_minor, tmp_ptr);
+    mptr.assign((size_t)n_major + 1, 0);
+    for (int64_t i = 0; i < nnz; ++i) mptr[(size_t)major[i] + 1]++;
+    for (int m = 0; m < n_major; ++m) mptr[(size_t)m + 1] += mptr[m];
+    order.resize((size_t)nnz);
+    std::vector<int64_t> cur(mptr.begin(), mptr.end() - 1);
+    for (int64_t j = 0; j < nnz; ++j) {
+        const int32_t pos = by_minor[(size_t)j];
+        order[(size_t)cur[major[pos]]++] = pos;
+    }
+}
+
 namespace {
 
 struct Chunk {
@@ -54,23 +72,9 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
     P.n_windows = n_windows;
     P.nnz = nnz;
 
-    // ---- sort positions by (major, minor): minor first, then stable by major ----
-    std::vector<int32_t> by_minor;
-    std::vector<int64_t> tmp_ptr;
-    counting_sort_positions(nnz, minor, n_minor, by_minor, tmp_ptr);
-    std::vector<int64_t> mptr((size_t)n_major + 1, 0);
-    for (int64_t i = 0; i < nnz; ++i) mptr[(size_t)major[i] + 1]++;
-    for (int m = 0; m < n_major; ++m) mptr[(size_t)m + 1] += mptr[m];
-    std::vector<int32_t> order((size_t)nnz);
-    {
-        std::vector<int64_t> cur(mptr.begin(), mptr.end() - 1);
-        for (int64_t j = 0; j < nnz; ++j) {
-            int32_t pos = by_minor[(size_t)j];
-            order[(size_t)cur[major[pos]]++] = pos;
-        }
-    }
-    by_minor.clear();
-    by_minor.shrink_to_fit();
+    std::vector<int32_t> order;
+    std::vector<int64_t> mptr;
+    sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
 
     // ---- windows over the minor index (equal width) ----
     const int64_t wwidth = ((int64_t)n_minor + n_windows - 1) / n_windows;
@@ -189,6 +193,131 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
             }
     }
 
+    if (keep_order) {
+        P.order.swap(order);
+        P.mptr.swap(mptr);
+    }
+}
+
+
+void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                     int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
+                     int target_tasks, bool keep_order, TilePlanHost &P)
+{
+    if (lpc < 1 || lpc > 64 || (64 % lpc) != 0) throw std::invalid_argument("lpc must divide 64");
+    if (waves_per_block < 1 || waves_per_block > 16) throw std::invalid_argument("waves_per_block in [1,16]");
+    if (win_rows < 1) throw std::invalid_argument("win_rows must be positive");
+    P = TilePlanHost();
+    P.n_major = n_major;
+    P.n_minor = n_minor;
+    P.lpc = lpc;
+    P.gpw = 64 / lpc;
+    P.wpb = waves_per_block;
+    P.gpb = P.gpw * P.wpb;
+    P.win_rows = win_rows;
+    P.n_windows = (n_minor + win_rows - 1) / win_rows;
+    P.nnz = nnz;
+    const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb;
+
+    std::vector<int32_t> order;
+    std::vector<int64_t> mptr;
+    sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
+
+    // rows by length, longest first (stable): a wave's groups then carry similar loads
+    std::vector<int32_t> rows((size_t)n_major);
+    std::iota(rows.begin(), rows.end(), 0);
+    std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
+        return (mptr[(size_t)a + 1] - mptr[a]) > (mptr[(size_t)b + 1] - mptr[b]);
+    });
+    P.n_blocks = ((int64_t)n_major + gpb - 1) / gpb;
+    P.block_rows.assign((size_t)P.n_blocks * gpb, -1);
+    for (int m = 0; m < n_major; ++m) P.block_rows[(size_t)m] = rows[(size_t)m];
+
+    // tasks: window ranges of `windows_per_task` windows, window-range major / block minor
+    int64_t wpt = 1;
+    if (target_tasks > 0) wpt = std::max<int64_t>(1, (int64_t)W * P.n_blocks / target_tasks);
+    wpt = std::min<int64_t>(wpt, W);
+    P.windows_per_task = (int)wpt;
+    const int n_ranges = (int)((W + wpt - 1) / wpt);
+    P.n_tasks = (int64_t)n_ranges * P.n_blocks;
+    P.n_partial_rows = P.n_tasks * gpb;
+    P.pstride = P.n_blocks * gpb;   // consecutive ranges of one block are n_blocks tasks apart
+    P.task_block.resize((size_t)P.n_tasks);
+    P.task_w0.resize((size_t)P.n_tasks);
+    P.task_w1.resize((size_t)P.n_tasks);
+    for (int r = 0; r < n_ranges; ++r)
+        for (int64_t b = 0; b < P.n_blocks; ++b) {
+            const size_t t = (size_t)r * P.n_blocks + b;
+            P.task_block[t] = (int32_t)b;
+            P.task_w0[t] = (int32_t)(r * wpt);
+            P.task_w1[t] = (int32_t)std::min<int64_t>((r + 1) * wpt, W);
+        }
+    P.pfirst.assign((size_t)n_major, 0);
+    P.pcount.assign((size_t)n_major, n_ranges);
+    for (int64_t b = 0; b < P.n_blocks; ++b)
+        for (int g = 0; g < gpb; ++g) {
+            const int32_t row = P.block_rows[(size_t)b * gpb + g];
+            if (row >= 0) P.pfirst[(size_t)row] = (int32_t)(b * gpb + g);
+        }
+
+    // per (block, wave, window): steps = ceil(longest segment / 2); then offsets and entries
+    P.steps.assign((size_t)P.n_blocks * wpb * W, 0);
+    std::vector<int32_t> seglen((size_t)W);
+    for (int64_t b = 0; b < P.n_blocks; ++b)
+        for (int g = 0; g < gpb; ++g) {
+            const int32_t row = P.block_rows[(size_t)b * gpb + g];
+            if (row < 0) continue;
+            std::fill(seglen.begin(), seglen.end(), 0);
+            for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) seglen[(size_t)(minor[order[(size_t)j]] / win_rows)]++;
+            uint16_t *st = P.steps.data() + ((size_t)b * wpb + g / gpw) * W;
+            for (int w = 0; w < W; ++w) {
+                const int32_t s = (seglen[(size_t)w] + 1) / 2;   // two nonzeros per step
+                if (s > 65535) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
+                if (s > st[w]) st[w] = (uint16_t)s;
+            }
+        }
+    std::vector<int64_t> wave_off((size_t)P.n_blocks * wpb + 1, 0);   // entries of (block, wave), window order
+    for (size_t bw = 0; bw < (size_t)P.n_blocks * wpb; ++bw) {
+        int64_t tot = 0;
+        for (int w = 0; w < W; ++w) tot += P.steps[bw * W + w];
+        wave_off[bw + 1] = wave_off[bw] + tot * gpw;
+    }
+    const int64_t total = wave_off.back();
+    P.entries.assign((size_t)total * 4, 0u);
+    P.task_wave_off.resize((size_t)P.n_tasks * wpb);
+    P.task_wave_end.resize((size_t)P.n_tasks * wpb);
+    for (int64_t b = 0; b < P.n_blocks; ++b)
+        for (int v = 0; v < wpb; ++v) {
+            const size_t bw = (size_t)b * wpb + v;
+            int64_t off = wave_off[bw];
+            for (int w = 0; w < W; ++w) {
+                const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
+                if (w % wpt == 0) P.task_wave_off[tv] = off;
+                off += (int64_t)P.steps[bw * W + w] * gpw;
+                P.task_wave_end[tv] = off;
+            }
+        }
+    // fill: walk each row's nonzeros in minor order; position inside its (window) segment = t
+    std::vector<int64_t> win_off((size_t)W);
+    for (int64_t b = 0; b < P.n_blocks; ++b)
+        for (int g = 0; g < gpb; ++g) {
+            const int32_t row = P.block_rows[(size_t)b * gpb + g];
+            if (row < 0) continue;
+            const size_t bw = (size_t)b * wpb + g / gpw;
+            int64_t off = wave_off[bw];
+            for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += (int64_t)P.steps[bw * W + w] * gpw; }
+            const int slot = g % gpw;
+            int32_t cur_w = -1, t = 0;
+            for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) {
+                const int32_t pos = order[(size_t)j];
+                const int32_t w = minor[pos] / win_rows;
+                if (w != cur_w) { cur_w = w; t = 0; }
+                uint32_t *e = P.entries.data() + ((size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot) * 4 + (size_t)(t & 1) * 2;
+                e[0] = (uint32_t)(minor[pos] - w * win_rows);
+                e[1] = f2u(val[pos]);
+                ++t;
+            }
+        }
     if (keep_order) {
         P.order.swap(order);
         P.mptr.swap(mptr);

@@ -54,6 +54,50 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
                       int n_major, int n_minor, int lpc, int chunk_len, int n_windows,
                       bool keep_order, SweepPlanHost &out);
 
+// ---------------------------------------------------------------------------------------
+// Tile plan: the layout for the LDS-staged sweep.
+//
+// The gather plan above pays one or two 128-byte L2->L1 line fills per nonzero (measured: the
+// texture-addresser / L1 fill path is the limiter, profiles/r01).  The tile plan removes that
+// traffic: the minor table is cut into WINDOWS of `win_rows` rows that fit in LDS; a workgroup
+// owns a BLOCK of `gpb` major rows (one per lane group, rows sorted by length so that a wave's
+// groups are balanced) and walks a range of windows (a TASK): stage the window's table slice
+// into LDS once, then every group streams its row's nonzeros of that window and gathers the
+// minor K-vectors from LDS.  A row's accumulators stay in registers for the whole task, so one
+// partial K-vector per (row, task) leaves the kernel.
+//
+//   entries   sliced-ELL per (block, wave, window): step-major uint4 {local0, val0, local1,
+//             val1} for the gpw groups of the wave; local = minor - window * win_rows
+//   steps     [ (block * wpb + wave) * n_windows + window ]  uint16 steps of that sub-slice
+//   task_*    block, first window, end window of each task; tasks are ordered window-range
+//             major / block minor so that concurrently running workgroups stage the same slice
+//   task_wave_off  [task * wpb + wave] offset (uint4 units) of the wave's entries at the task's
+//             first window
+//   partial row of (task t, group g) = t * gpb + g;  a major row's partial rows are
+//             pfirst[row] + j * pstride, j < pcount[row]
+struct TilePlanHost {
+    int n_major = 0, n_minor = 0;
+    int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
+    int win_rows = 0, n_windows = 0, windows_per_task = 0;
+    int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
+    std::vector<uint32_t> entries;
+    std::vector<uint16_t> steps;
+    std::vector<int32_t> block_rows;      // [n_blocks * gpb] major id or -1
+    std::vector<int32_t> task_block, task_w0, task_w1;
+    std::vector<int64_t> task_wave_off, task_wave_end;
+    std::vector<int32_t> pfirst, pcount;  // [n_major]
+    std::vector<int32_t> order;           // [nnz] (major, minor)-sorted position -> caller's COO position
+    std::vector<int64_t> mptr;            // [n_major + 1]
+};
+
+void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                     int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
+                     int target_tasks, bool keep_order, TilePlanHost &out);
+
+// positions sorted by (major, minor) and the per-major run pointers
+void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
+                         std::vector<int32_t> &order, std::vector<int64_t> &mptr);
+
 // Stable counting sort of positions by key: order[j] = original position of the j-th
 // smallest key; ptr[k]..ptr[k+1] is the run of key k.
 void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vector<int32_t> &order,

@@ -71,20 +71,59 @@ template <typename T, int LPC> __device__ __forceinline__ int factor_of(int r, i
     return ((r / Vec16<T>::N) * LPC + sub) * Vec16<T>::N + (r % Vec16<T>::N);
 }
 
+// Cross-lane exchange inside a lane group with DPP (no LDS traffic): after each step every lane
+// of the 2^step-lane sub-group holds the same value, so quad_perm (xor 1, xor 2), then
+// row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) complete an all-reduce over 16 lanes.
+template <int STEP> __device__ __forceinline__ int dpp_partner(int v)
+{
+    if (STEP == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);                 // row_mirror
+}
+template <int STEP> __device__ __forceinline__ float partner(float v)
+{
+    return __int_as_float(dpp_partner<STEP>(__float_as_int(v)));
+}
+template <int STEP> __device__ __forceinline__ double partner(double v)
+{
+    const int lo = dpp_partner<STEP>(__double2loint(v));
+    const int hi = dpp_partner<STEP>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 template <typename T, int LPC> __device__ __forceinline__ T group_sum(T v)
 {
-#pragma unroll
-    for (int m = 1; m < LPC; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (LPC >= 2) v += partner<0>(v);
+    if (LPC >= 4) v += partner<1>(v);
+    if (LPC >= 8) v += partner<2>(v);
+    if (LPC >= 16) v += partner<3>(v);
     return v;
 }
 template <typename T, int LPC> __device__ __forceinline__ T group_max(T v)
 {
-#pragma unroll
-    for (int m = 1; m < LPC; m <<= 1) {
-        const T o = __shfl_xor(v, m, 64);
-        v = o > v ? o : v;
-    }
+    if (LPC >= 2) { const T o = partner<0>(v); v = o > v ? o : v; }
+    if (LPC >= 4) { const T o = partner<1>(v); v = o > v ? o : v; }
+    if (LPC >= 8) { const T o = partner<2>(v); v = o > v ? o : v; }
+    if (LPC >= 16) { const T o = partner<3>(v); v = o > v ? o : v; }
     return v;
+}
+
+// x / s for s known to be a normal positive number: hardware reciprocal + Newton steps instead
+// of the IEEE division sequence (no scaling / fix-up needed here).  <= 2 ulp.
+__device__ __forceinline__ double fast_div(double x, double s)
+{
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    r = fma(fma(-s, r, 1.0), r, r);
+    const double q = x * r;
+    return fma(fma(-s, q, x), r, q);
+}
+__device__ __forceinline__ float fast_div(float x, float s)
+{
+    float r = __builtin_amdgcn_rcpf(s);
+    r = fmaf(fmaf(-s, r, 1.0f), r, r);
+    const float q = x * r;
+    return fmaf(fmaf(-s, q, x), r, q);
 }
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -103,11 +142,108 @@ __device__ __forceinline__ T group_dot(const T (&x)[KL], const T (&y)[KL])
     return group_sum<T, LPC>(s);
 }
 
+
+// Cold path shared by both sweeps.  When the product-form normaliser of ANY nonzero of a lane
+// group underflowed, the group's whole accumulator is recomputed in the reference's own
+// max-shifted log-domain form (hpf_numba.py:98-112) from the E[log] tables and replaces the
+// fast result -- no atomics, no double counting, still deterministic.  Deliberately register-
+// lean (tables are re-read from L2 three times per nonzero): it must not cost the hot loop
+// occupancy.  acc[] receives sum x * phi_k directly (no multiplication by Et afterwards).
+template <typename T, int NV, int LPC>
+__device__ __forceinline__ void slow_nonzero(const T *__restrict__ lt_row, const T *__restrict__ lm_row, int sub,
+                                          int K, T x, T (&acc)[NV * Vec16<T>::N])
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int VEC = Vec16<T>::N;
+    const V *__restrict__ pt = reinterpret_cast<const V *>(lt_row) + sub;
+    const V *__restrict__ pm = reinterpret_cast<const V *>(lm_row) + sub;
+    T mx = -INFINITY;
+#pragma unroll 1
+    for (int q = 0; q < NV; ++q) {
+        T a[VEC], b[VEC];
+        Vec16<T>::unpack(pt[q * LPC], a);
+        Vec16<T>::unpack(pm[q * LPC], b);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            if ((q * LPC + sub) * VEC + v < K) { const T l = a[v] + b[v]; mx = l > mx ? l : mx; }
+    }
+    mx = group_max<T, LPC>(mx);
+    double ss = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < NV; ++q) {
+        T a[VEC], b[VEC];
+        Vec16<T>::unpack(pt[q * LPC], a);
+        Vec16<T>::unpack(pm[q * LPC], b);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            if ((q * LPC + sub) * VEC + v < K) ss += exp((double)(a[v] + b[v] - mx));
+    }
+    ss = group_sum<double, LPC>(ss);
+    const double scale = (double)x / ss;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        T a[VEC], b[VEC];
+        Vec16<T>::unpack(pt[q * LPC], a);
+        Vec16<T>::unpack(pm[q * LPC], b);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+            if ((q * LPC + sub) * VEC + v < K) acc[q * VEC + v] += (T)(scale * exp((double)(a[v] + b[v] - mx)));
+    }
+}
+
+// whole-group recompute for the gather plan: one chunk, `steps` uint4 steps `stride` apart
+template <typename T, int NV, int LPC>
+__device__ __noinline__ void slow_chunk(const uint4 *__restrict__ ep, int steps, int stride,
+                                        const T *__restrict__ lt_row, const T *__restrict__ log_minor, int sub,
+                                        int K, T *__restrict__ out_row)
+{
+    constexpr int KL = NV * Vec16<T>::N;
+    constexpr int KP = KL * LPC;
+    T acc[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) acc[k] = T(0);
+#pragma unroll 1
+    for (int p = 0; p < steps; ++p) {
+        const uint4 ee = ep[(size_t)p * stride];
+        if (__uint_as_float(ee.y) > 0.f)
+            slow_nonzero<T, NV, LPC>(lt_row, log_minor + (size_t)ee.x * KP, sub, K, (T)__uint_as_float(ee.y), acc);
+        if (__uint_as_float(ee.w) > 0.f)
+            slow_nonzero<T, NV, LPC>(lt_row, log_minor + (size_t)ee.z * KP, sub, K, (T)__uint_as_float(ee.w), acc);
+    }
+    store_lane<T, NV, LPC>(out_row, sub, acc);
+}
+// ... and for the tile plan: a row's nonzeros over the windows [w0, w1) of its task
+template <typename T, int NV, int LPC>
+__device__ __noinline__ void slow_task_row(const uint4 *__restrict__ ep, const uint16_t *__restrict__ st, int w0,
+                                           int w1, int win_rows, int stride, const T *__restrict__ lt_row,
+                                           const T *__restrict__ log_minor, int sub, int K, T *__restrict__ out_row)
+{
+    constexpr int KL = NV * Vec16<T>::N;
+    constexpr int KP = KL * LPC;
+    T acc[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) acc[k] = T(0);
+#pragma unroll 1
+    for (int w = w0; w < w1; ++w) {
+        const int steps = st[w];
+        const T *__restrict__ lm = log_minor + (size_t)w * win_rows * KP;
+#pragma unroll 1
+        for (int p = 0; p < steps; ++p) {
+            const uint4 ee = ep[(size_t)p * stride];
+            if (__uint_as_float(ee.y) > 0.f)
+                slow_nonzero<T, NV, LPC>(lt_row, lm + (size_t)ee.x * KP, sub, K, (T)__uint_as_float(ee.y), acc);
+            if (__uint_as_float(ee.w) > 0.f)
+                slow_nonzero<T, NV, LPC>(lt_row, lm + (size_t)ee.z * KP, sub, K, (T)__uint_as_float(ee.w), acc);
+        }
+        ep += (size_t)steps * stride;
+    }
+    store_lane<T, NV, LPC>(out_row, sub, acc);
+}
+
 // MODE_PHI : acc_k += (x / s) * Eb[minor,k];  partial row = acc_k * Et[major,k]  -- this
 //            chunk's share of sum x*phi_k (hpf_numba.py:97-112 fused with :152-155).
-//            Nonzeros whose s underflows are skipped here and redone after the loop in the
-//            reference's own max-shifted log-domain form from the E[log] tables (cold path,
-//            atomics into `extra`, flagged for the update kernel).
+//            If the normaliser s of any nonzero of the group underflows, the group's result is
+//            recomputed in the reference's own max-shifted log-domain form (slow_nonzero).
 // MODE_LLH : sum over the chunk of x*log(r) - r, r = sum_k E[theta]E[beta]
 //            (hpf_numba.py:43-50 minus the constant gammaln term); one double per wave.
 template <typename T, int NV, int LPC, int MODE>
@@ -154,8 +290,8 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs<T> a)
         const T s1 = group_dot<T, KL, LPC>(tm, b1);
         if (MODE == MODE_PHI) {
             const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;   // false for NaN too
-            const T w0 = (x0 > T(0) && ok0) ? x0 / s0 : T(0);
-            const T w1 = (x1 > T(0) && ok1) ? x1 / s1 : T(0);
+            const T w0 = (x0 > T(0) && ok0) ? fast_div(x0, s0) : T(0);
+            const T w1 = (x1 > T(0) && ok1) ? fast_div(x1, s1) : T(0);
             any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
 #pragma unroll
             for (int k = 0; k < KL; ++k) acc[k] += w0 * b0[k] + w1 * b1[k];
@@ -173,53 +309,15 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs<T> a)
     }
 
     if (live) {
-#pragma unroll
-        for (int k = 0; k < KL; ++k) acc[k] *= tm[k];
         const int nat = a.chunk_natid[(size_t)slice * CPW + slot];
-        store_lane<T, NV, LPC>(a.partials + (size_t)nat * KP, sub, acc);
-    }
-
-    // ---- cold path: nonzeros whose product-form normaliser underflowed -------------------
-    if (__builtin_expect(__any(any_bad), 0)) {
-        if (!any_bad) return;      // whole groups leave together (any_bad is group-uniform)
-        T lt[KL];
-        load_lane<T, NV, LPC>(a.log_major + (size_t)major * KP, sub, lt);
-#pragma unroll 1
-        for (int p = 0; p < steps; ++p) {
-            const uint4 ee = ep[(size_t)p * CPW];
-#pragma unroll 1
-            for (int u = 0; u < 2; ++u) {
-                const unsigned idx = u ? ee.z : ee.x;
-                const T x = (T)__uint_as_float(u ? ee.w : ee.y);
-                T b[KL];
-                load_lane<T, NV, LPC>(tabm + (size_t)idx * KP, sub, b);
-                const T s = group_dot<T, KL, LPC>(tm, b);     // same arithmetic as the hot loop
-                if (!(x > T(0)) || s >= tiny) continue;
-                // the reference's form: softmax_k of Elt + Elb with a max shift (hpf_numba.py:98-112)
-                T lr[KL];
-                load_lane<T, NV, LPC>(a.log_minor + (size_t)idx * KP, sub, lr);
-                T mx = -INFINITY;
+        T *out_row = a.partials + (size_t)nat * KP;
+        if (__builtin_expect(any_bad, 0)) {   // group-uniform; rare: see slow_nonzero
+            slow_chunk<T, NV, LPC>(ep, steps, CPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K, out_row);
+        } else {
 #pragma unroll
-                for (int k = 0; k < KL; ++k) {
-                    lr[k] += lt[k];
-                    if (factor_of<T, LPC>(k, sub) < a.K) mx = lr[k] > mx ? lr[k] : mx;
-                }
-                mx = group_max<T, LPC>(mx);
-                T ss = T(0);
-#pragma unroll
-                for (int k = 0; k < KL; ++k) {
-                    lr[k] = factor_of<T, LPC>(k, sub) < a.K ? (T)exp((double)(lr[k] - mx)) : T(0);
-                    ss += lr[k];
-                }
-                ss = group_sum<T, LPC>(ss);
-#pragma unroll
-                for (int k = 0; k < KL; ++k) {
-                    const int f = factor_of<T, LPC>(k, sub);
-                    if (f < a.K) atomicAdd(a.extra + (size_t)major * KP + f, (T)((double)x * (double)lr[k] / (double)ss));
-                }
-            }
+            for (int k = 0; k < KL; ++k) acc[k] *= tm[k];
+            store_lane<T, NV, LPC>(out_row, sub, acc);
         }
-        *a.extra_flag = 1;
     }
 }
 
@@ -290,6 +388,187 @@ __global__ __launch_bounds__(256) void random_phi_sweep_kernel(SweepArgs<T> a, u
     store_lane<T, NV, LPC>(a.partials + (size_t)nat * KP, sub, out);
 }
 
+
+// ------------------------------------------------------------- the LDS-staged sweep
+// One workgroup = one task of a tile plan (plan.h): a block of major rows (one per lane
+// group) x a range of minor windows.  Per window: the window's slice of the minor table is
+// copied HBM/L2 -> LDS once (coalesced 16-byte lanes), then every group streams its row's
+// nonzeros of that window (sliced-ELL, coalesced, non-temporal) and gathers the minor
+// K-vectors from LDS with ds_read_b128 -- no per-nonzero L2->L1 line fills.  Two workgroups
+// share a CU (<= 64 KiB LDS each): one stages while the other computes.
+template <typename T, int NV, int LPC, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int KL = NV * VEC;
+    constexpr int GPW = 64 / LPC;
+    constexpr int KP = KL * LPC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *win = reinterpret_cast<T *>(lds_raw);
+
+    const int task = blockIdx.x;
+    const int blk = a.task_block[task], w0 = a.task_w0[task], w1 = a.task_w1[task];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane / LPC, sub = lane % LPC;
+    const int gpb = GPW * a.wpb;
+    const int g = wv * GPW + grp;
+    const int major = a.block_rows[(size_t)blk * gpb + g];
+    const bool live = major >= 0;
+
+    T tm[KL], acc[KL];
+#pragma unroll
+    for (int k = 0; k < KL; ++k) { tm[k] = T(0); acc[k] = T(0); }
+    if (MODE != MODE_RANDOM && live) load_lane<T, NV, LPC>(a.tab_major + (size_t)major * KP, sub, tm);
+    double llh = 0.0;
+    bool any_bad = false;
+    const T tiny = Vec16<T>::tiny();
+
+    const uint4 *__restrict__ ep = a.entries + a.task_wave_off[(size_t)task * a.wpb + wv] + grp;
+    const uint16_t *__restrict__ st = a.steps + ((size_t)blk * a.wpb + wv) * a.n_windows;
+
+    for (int w = w0; w < w1; ++w) {
+        const int steps = st[w];
+        if (MODE != MODE_RANDOM) {
+            __syncthreads();                       // previous window fully consumed
+            const int r0 = w * a.win_rows;
+            const int nr = min(a.win_rows, a.n_minor - r0);
+            const V *__restrict__ src = reinterpret_cast<const V *>(a.tab_minor + (size_t)r0 * KP);
+            V *dst = reinterpret_cast<V *>(win);
+            const int nvec = nr * (KP / VEC);
+            for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+            __syncthreads();
+        }
+        if (MODE == MODE_RANDOM) {
+            // t = 0 responsibilities (reference scHPF_.py:652-655) from the counter-based generator
+            for (int p = 0; p < steps; ++p) {
+                const uint4 e = ep[(size_t)p * GPW];
+#pragma unroll 1
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned minor = (unsigned)(w * a.win_rows) + (u ? e.z : e.x);
+                    const double x = (double)__uint_as_float(u ? e.w : e.y);
+                    if (!(x > 0.0)) continue;
+                    const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
+                    const uint64_t gene = a.major_is_cell ? (uint64_t)minor : (uint64_t)major;
+                    double d[KL];
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KL; ++k) {
+                        const int f = factor_of<T, LPC>(k, sub);
+                        d[k] = f < a.K ? exp1_draw(a.seed, cell, gene, (unsigned)f) : 0.0;
+                        s += d[k];
+                    }
+                    s = group_sum<double, LPC>(s);
+                    const double wgt = x / s;
+#pragma unroll
+                    for (int k = 0; k < KL; ++k) acc[k] += (T)(wgt * d[k]);
+                }
+            }
+        } else if (steps > 0) {
+            // wide rows: one nonzero in flight at a time keeps the register budget (b once)
+            constexpr bool PAIR = KL * (int)sizeof(T) <= 96;
+            uint4 e = stream_load(ep);
+            for (int p = 0; p < steps; ++p) {
+                const uint4 c = e;
+                if (p + 1 < steps) e = stream_load(ep + (size_t)(p + 1) * GPW);
+                if (PAIR) {
+                    T b0[KL], b1[KL];
+                    load_lane<T, NV, LPC>(win + (size_t)c.x * KP, sub, b0);
+                    load_lane<T, NV, LPC>(win + (size_t)c.z * KP, sub, b1);
+                    const T x0 = (T)__uint_as_float(c.y);
+                    const T x1 = (T)__uint_as_float(c.w);
+                    const T s0 = group_dot<T, KL, LPC>(tm, b0);
+                    const T s1 = group_dot<T, KL, LPC>(tm, b1);
+                    if (MODE == MODE_PHI) {
+                        const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;
+                        const T q0 = (x0 > T(0) && ok0) ? fast_div(x0, s0) : T(0);
+                        const T q1 = (x1 > T(0) && ok1) ? fast_div(x1, s1) : T(0);
+                        any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
+#pragma unroll
+                        for (int k = 0; k < KL; ++k) acc[k] += q0 * b0[k] + q1 * b1[k];
+                    } else {
+                        if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
+                        if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
+                    }
+                } else {
+#pragma unroll 1
+                    for (int u = 0; u < 2; ++u) {
+                        T b[KL];
+                        load_lane<T, NV, LPC>(win + (size_t)(u ? c.z : c.x) * KP, sub, b);
+                        const T x = (T)__uint_as_float(u ? c.w : c.y);
+                        const T s = group_dot<T, KL, LPC>(tm, b);
+                        if (MODE == MODE_PHI) {
+                            const bool ok = s >= tiny;
+                            const T q = (x > T(0) && ok) ? fast_div(x, s) : T(0);
+                            any_bad |= x > T(0) && !ok;
+#pragma unroll
+                            for (int k = 0; k < KL; ++k) acc[k] += q * b[k];
+                        } else {
+                            if (x > T(0)) llh += (double)x * log((double)s) - (double)s;
+                        }
+                    }
+                }
+            }
+        }
+        ep += (size_t)steps * GPW;
+    }
+
+    if (MODE == MODE_LLH) {
+        if (sub != 0) llh = 0.0;
+        llh = wave_sum(llh);
+        if (lane == 0) a.wave_out[(size_t)task * a.wpb + wv] = llh;
+        return;
+    }
+    T *out_row = a.partials + ((size_t)task * gpb + g) * KP;
+    if (MODE == MODE_PHI && __builtin_expect(any_bad, 0)) {   // group-uniform; rare: see slow_nonzero
+        slow_task_row<T, NV, LPC>(a.entries + a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
+                                  a.win_rows, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K, out_row);
+        return;
+    }
+    if (MODE == MODE_PHI) {
+#pragma unroll
+        for (int k = 0; k < KL; ++k) acc[k] *= tm[k];
+    }
+    // dead groups write zeros too: every partial row of the task is defined after a sweep
+    store_lane<T, NV, LPC>(out_row, sub, acc);
+}
+
+template <typename T, int NV, int LPC, int MAXT>
+static hipError_t launch_tile_b(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
+                                hipStream_t st)
+{
+    dim3 grid((unsigned)n_tasks), block((unsigned)threads);
+    if (lds_bytes > 64 * 1024) {   // opt in to the full 160 KiB of a CU, once per instantiation
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
+    if (mode == MODE_PHI)
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT>), grid, block, lds_bytes, st, a);
+    else if (mode == MODE_LLH)
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT>), grid, block, lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_RANDOM, MAXT>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+// the launch bound caps the register budget: 1024 threads -> 128 VGPRs, 768 -> 168, 512 -> 256
+template <typename T, int NV, int LPC>
+static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
+                                hipStream_t st)
+{
+    if (n_tasks == 0) return hipSuccess;
+    if (threads <= 512) return launch_tile_b<T, NV, LPC, 512>(a, mode, n_tasks, threads, lds_bytes, st);
+    if (threads <= 768) return launch_tile_b<T, NV, LPC, 768>(a, mode, n_tasks, threads, lds_bytes, st);
+    return launch_tile_b<T, NV, LPC, 1024>(a, mode, n_tasks, threads, lds_bytes, st);
+}
+
 // ------------------------------------------------------------------------ launchers
 template <typename T, int NV, int LPC>
 static hipError_t launch_sweep_t(const SweepArgs<T> &a, int mode, int64_t n_waves, hipStream_t st)
@@ -329,7 +608,9 @@ static hipError_t launch_random_t(const SweepArgs<T> &a, uint64_t seed, int majo
     case 4: { constexpr int NV = 4; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
     case 5: { constexpr int NV = 5; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
     case 6: { constexpr int NV = 6; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 7: { constexpr int NV = 7; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
     case 8: { constexpr int NV = 8; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 10: { constexpr int NV = 10; SCHPF_FOR_LPC(lpc, CALLEXPR) }          \
     default: return hipErrorInvalidValue;                                     \
     }
 
@@ -343,6 +624,12 @@ hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t se
                              int64_t n_waves, hipStream_t st)
 {
     SCHPF_DISPATCH(nv, lpc, (launch_random_t<T, NV, LPC>(a, seed, major_is_cell, n_waves, st)))
+}
+template <typename T>
+hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int64_t n_tasks, int threads,
+                             size_t lds_bytes, hipStream_t st)
+{
+    SCHPF_DISPATCH(nv, lpc, (launch_tile_t<T, NV, LPC>(a, mode, n_tasks, threads, lds_bytes, st)))
 }
 
 }  // namespace schpf

@@ -99,3 +99,52 @@ def test_plan_empty_rows_and_single_nonzero():
     om, on, ov, onat, ow, cptr, stats = expand([3], [2], [7.0], 6, 5, 1, 16, 1)
     assert (om[0], on[0], ov[0]) == (3, 2, 7.0)
     assert list(cptr) == [0, 0, 0, 0, 1, 1, 1] and stats[0] == 1
+
+
+def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_tasks):
+    lib = _lib.load()
+    nnz = len(val)
+    major = np.ascontiguousarray(major, np.int32)
+    minor = np.ascontiguousarray(minor, np.int32)
+    val = np.ascontiguousarray(val, np.float32)
+    om = np.empty(nnz, np.int32); on = np.empty(nnz, np.int32); ov = np.empty(nnz, np.float32)
+    oprow = np.empty(nnz, np.int32); otask = np.empty(nnz, np.int32)
+    pfirst = np.empty(n_major, np.int32); pcount = np.empty(n_major, np.int32)
+    stats = (ctypes.c_int64 * 6)()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _lib.check(lib.schpf_debug_tile_expand(nnz, p(major), p(minor), p(val), n_major, n_minor, lpc, wpb,
+                                           win_rows, target_tasks, p(om), p(on), p(ov), p(oprow), p(otask),
+                                           p(pfirst), p(pcount), stats))
+    return om, on, ov, oprow, otask, pfirst, pcount, [int(s) for s in stats]
+
+
+@pytest.mark.parametrize("lpc,wpb,win_rows,tasks", [(4, 8, 64, 64), (2, 4, 37, 1), (1, 1, 1000, 7), (8, 2, 5, 1000),
+                                                  (16, 8, 300, 16)])
+def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks):
+    X = synthetic_counts(257, 1031, 0.04, seed=5)
+    perm = np.random.RandomState(0).permutation(X.nnz)
+    row, col, val = X.row[perm], X.col[perm], X.data[perm].astype(np.float32)
+    for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
+        om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, tasks)
+        n_tasks, n_blocks, n_windows, pstride, slots, wpt = st
+        key_in = np.sort(major.astype(np.int64) * nm + minor)
+        key_out = np.sort(om.astype(np.int64) * nm + on)
+        assert np.array_equal(key_in, key_out)                       # every nonzero exactly once
+        oi = np.lexsort((minor, major)); oo = np.lexsort((on, om))
+        assert np.array_equal(val[oi], ov[oo])
+        # a nonzero's partial row is one of its major's strided partial rows, and the right one
+        j = (oprow - pfirst[om]) // pstride
+        assert np.array_equal(pfirst[om] + j * pstride, oprow)
+        assert np.all(j >= 0) and np.all(j < pcount[om])
+        assert np.array_equal(j, (on // win_rows) // wpt)            # task range <-> window
+        assert n_windows == -(-nm // win_rows)
+        assert n_tasks == n_blocks * -(-n_windows // wpt)
+        # partial rows are exclusive to one major
+        owner = np.full(n_tasks * (64 // lpc) * wpb, -1)
+        owner[oprow] = om
+        assert np.array_equal(owner[oprow], om)
+
+
+def test_tile_plan_tiny():
+    om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile([3], [2], [7.0], 6, 5, 4, 8, 64, 2048)
+    assert (om[0], on[0], ov[0]) == (3, 2, 7.0) and st[0] == 1 and pcount[3] == 1

@@ -15,6 +15,14 @@ from conftest import load_golden, golden_coo, synthetic_counts
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["tile", "gather"])
+def plan_kind(request, monkeypatch):
+    """Every engine test runs on both sweep implementations: the LDS-staged tile plan and
+    the L2-gather plan (selected by the library from SCHPF_PLAN at upload time)."""
+    monkeypatch.setenv("SCHPF_PLAN", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def amd():
     import schpf_amd

@@ -27,7 +27,7 @@ def _rt(dtype, f64=1e-7, f32=1e-5):
 def test_digamma_gammaln_vs_scipy_values(hip):
     g = load_golden("psi_gammaln.npz")
     x = g["x"]
-    assert_allclose(hip.psi(x), g["psi"], rtol=2e-15, atol=1e-15)
+    assert_allclose(hip.psi(x), g["psi"], rtol=4e-15, atol=4e-15)
     assert_allclose(hip.cgammaln(x), g["gammaln"], rtol=5e-15, atol=5e-15)
     n = int(g["n_test_points"])      # the reference's own points, default rtol 1e-7
     for v, p, l in zip(x[:n], g["psi"][:n], g["gammaln"][:n]):

@@ -54,7 +54,7 @@ def run(X, K, setting, steps=10):
                       "gene_ms": round(gene, 4), "upd_ms": round(upd, 4),
                       "frac_hbm": round(b / (wall * 1e-3) / 8e12, 4), "loss": loss,
                       "upload_s": round(t_up, 2),
-                      "plan": {k: info[k] for k in ("KL", "LPC", "chunk_len", "windows_cell", "windows_gene")}}),
+                      "plan": info}),
           flush=True)
 
 
