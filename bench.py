@@ -112,8 +112,8 @@ def cpu_baseline(X, K, dtype, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -58,6 +58,7 @@ SIGNATURES = {
 STRING_FUNCS = ("schpf_last_error", "schpf_version")
 
 _lib = None
+HIP_RUNTIME = None
 
 
 class SchpfHipError(RuntimeError):
@@ -74,14 +75,48 @@ def build(force=False):
     return LIB_PATH
 
 
+def _hip_runtime_path():
+    """The ONE HIP runtime this process should use.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (torch/lib);
+    loading a second copy from /opt/rocm next to it gives two HSA runtimes in one process:
+    whichever initialises second may see no GPU, and memory allocated by one is unknown to the
+    other (RCCL on our exchange buffer).  libschpf_hip.so therefore has no DT_NEEDED on the
+    runtime; we pick it here: $SCHPF_HIP_RUNTIME, else torch's bundled copy when torch is
+    installed (found without importing torch), else the system ROCm.
+    """
+    override = os.environ.get("SCHPF_HIP_RUNTIME")
+    if override:
+        return override
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                return cand
+    except (ImportError, ValueError):
+        pass
+    for cand in ("/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"):
+        if cand.startswith("/") and not os.path.exists(cand):
+            continue
+        return cand
+    return "libamdhip64.so"
+
+
 def load():
-    global _lib
+    global _lib, HIP_RUNTIME
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SchpfHipError(
             "libschpf_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    HIP_RUNTIME = _hip_runtime_path()
+    try:
+        ctypes.CDLL(HIP_RUNTIME, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:
+        raise SchpfHipError("cannot load the HIP runtime %s: %s" % (HIP_RUNTIME, e))
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -278,3 +278,59 @@ def test_engine_argument_errors(amd):
         eng.upload(X)
         with pytest.raises(ValueError):
             eng.set_gamma("theta", np.ones((50, 2)), np.ones((50, 2)))
+
+
+@pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
+def test_sharded_protocol_two_engines_on_one_gpu(amd, oracle, flags):
+    """Cells split over two engines (as two ranks would hold them); the all-reduce is played by
+    adding the two exchange buffers through torch views of the library's device memory -- the
+    same views bench.py hands to RCCL.  Result must match the unsharded oracle."""
+    import torch
+    from schpf_amd.sharded import row_partition, take_rows, exchange_tensor_of
+    X = synthetic_counts(600, 400, 0.08, seed=13)
+    K, a, c = 12, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=4)
+    xphi0 = X.data[:, None] * np.random.dirichlet(np.ones(K), X.nnz)
+    bounds = row_partition(X, 2)
+    engines, views = [], []
+    for r in range(2):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        Xl, keep = take_rows(X, lo, hi)
+        eng = amd.DeviceCAVI(hi - lo, X.shape[1], K, dtype=np.float64)
+        eng.upload(Xl)
+        eng.set_hypers(a, c, bp, dp)
+        eng.set_gamma("xi", st.xi_shape[lo:hi], st.xi_rate[lo:hi])
+        eng.set_gamma("theta", st.theta_shape[lo:hi], st.theta_rate[lo:hi])
+        eng.set_gamma("eta", st.eta_shape, st.eta_rate)
+        eng.set_gamma("beta", st.beta_shape, st.beta_rate)
+        eng.init_phi_host(xphi0[keep])
+        engines.append(eng)
+        views.append(exchange_tensor_of(eng, 0))
+    assert views[0].numel() == 400 * K + K and views[0].dtype == torch.float64
+    for t in range(3):
+        for eng in engines:
+            eng.step_local(**flags)
+            eng.synchronize()
+        if not flags.get("freeze_genes"):
+            total = views[0] + views[1]
+            views[0].copy_(total); views[1].copy_(total)
+            torch.cuda.synchronize()
+        for eng in engines:
+            eng.step_finish(**flags)
+        oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp, xphi=xphi0 if t == 0 else None, **flags)
+    ths = np.concatenate([e.get_gamma("theta")[0] for e in engines])
+    thr = np.concatenate([e.get_gamma("theta")[1] for e in engines])
+    assert_allclose(ths, st.theta_shape, rtol=1e-11)
+    assert_allclose(thr, st.theta_rate, rtol=1e-11)
+    for e in engines:
+        bes, ber = e.get_gamma("beta")
+        assert_allclose(bes, st.beta_shape, rtol=1e-11)
+        assert_allclose(ber, st.beta_rate, rtol=1e-11)
+        assert_allclose(e.get_gamma("eta")[1], st.eta_rate, rtol=1e-11)
+    terms = [e.loss_terms() for e in engines]
+    loss = -(sum(t[0] for t in terms) - sum(t[1] for t in terms)) / sum(t[2] for t in terms)
+    want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                         st.beta_shape, st.beta_rate)
+    assert_allclose(loss, want, rtol=1e-11)
+    for e in engines:
+        e.close()

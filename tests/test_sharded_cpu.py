@@ -1,0 +1,106 @@
+"""The cells-sharded iteration (schpf_amd/sharded.py) on CPU: world_size 2, gloo backend, an
+oracle-backed engine per rank.  Two ranks holding row blocks of X must reproduce the
+unsharded oracle (up to summation order: the gene-side sums are added per shard first)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from numpy.testing import assert_allclose
+
+from conftest import synthetic_counts
+from schpf_amd.sharded import ShardedCAVI, row_partition, take_rows
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_row_partition_balances_nonzeros():
+    X = synthetic_counts(500, 80, 0.1, seed=1)
+    for world in (1, 2, 3, 8):
+        b = row_partition(X, world)
+        assert b[0] == 0 and b[-1] == 500 and np.all(np.diff(b) >= 0) and len(b) == world + 1
+        counts = [take_rows(X, b[r], b[r + 1])[0].nnz for r in range(world)]
+        assert sum(counts) == X.nnz
+        assert max(counts) - min(counts) <= 2 * X.nnz / 500 * 3 + 40       # within a few rows' worth
+    sub, keep = take_rows(X, 10, 20)
+    assert sub.shape == (10, 80) and np.array_equal(X.row[keep] - 10, sub.row)
+
+
+def _worker(rank, world, port, flags, dtype_name, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _oracle_engine import OracleEngine
+    from oracle import hpf_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dtype = np.dtype(dtype_name)
+    X = synthetic_counts(240, 150, 0.12, seed=7)
+    K, a, c = 6, 0.3, 0.3
+    np.random.seed(3)                       # every rank draws the same global initialisation
+    bp, dp, st = orc.setup_state(X, K, dtype, a, 1.0, c, 1.0)
+    st.xi_shape[:] = 1.0 + K * a
+    st.eta_shape[:] = 1.0 + K * c
+    xphi0 = X.data[:, None] * np.random.dirichlet(np.ones(K), X.nnz)
+    bounds = row_partition(X, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    Xl, keep = take_rows(X, lo, hi)
+    eng = OracleEngine(Xl, K, dtype)
+    eng.set_hypers(a, c, bp, dp)
+    eng.set_gamma("xi", st.xi_shape[lo:hi], st.xi_rate[lo:hi])
+    eng.set_gamma("eta", st.eta_shape, st.eta_rate)
+    eng.set_gamma("beta", st.beta_shape, st.beta_rate)
+    eng.set_gamma("theta", st.theta_shape[lo:hi], st.theta_rate[lo:hi])
+    drv = ShardedCAVI(eng, eng.exchange)
+    eng.init_phi_host(xphi0[keep])          # t = 0: the caller's Dirichlet draws, local rows
+    losses = []
+    for t in range(4):
+        drv.step(**flags)
+        losses.append(drv.mean_negative_pois_llh())
+    ths, thr = eng.get_gamma("theta")
+    bes, ber = eng.get_gamma("beta")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), lo=lo, hi=hi, ths=ths, thr=thr, bes=bes, ber=ber,
+             eta_r=eng.get_gamma("eta")[1], xi_r=eng.get_gamma("xi")[1], losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
+@pytest.mark.parametrize("dtype_name", ["float64", "float32"])
+def test_two_ranks_reproduce_the_unsharded_oracle(tmp_path, oracle, flags, dtype_name):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), flags, dtype_name, str(tmp_path)), nprocs=world, join=True)
+    dtype = np.dtype(dtype_name)
+    X = synthetic_counts(240, 150, 0.12, seed=7)
+    K, a, c = 6, 0.3, 0.3
+    np.random.seed(3)
+    bp, dp, st = oracle.setup_state(X, K, dtype, a, 1.0, c, 1.0)
+    st.xi_shape[:] = 1.0 + K * a
+    st.eta_shape[:] = 1.0 + K * c
+    xphi0 = X.data[:, None] * np.random.dirichlet(np.ones(K), X.nnz)
+    want_losses = []
+    for t in range(4):
+        oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp, xphi=xphi0 if t == 0 else None, **flags)
+        want_losses.append(oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                                         st.beta_shape, st.beta_rate))
+    tol = 2e-4 if dtype == np.float32 else 1e-11
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert parts[0]["hi"] == parts[1]["lo"] and parts[1]["hi"] == 240
+    ths = np.concatenate([p["ths"] for p in parts]); thr = np.concatenate([p["thr"] for p in parts])
+    assert_allclose(ths, st.theta_shape, rtol=tol)
+    assert_allclose(thr, st.theta_rate, rtol=tol)
+    assert_allclose(np.concatenate([p["xi_r"] for p in parts]), st.xi_rate, rtol=tol)
+    for p in parts:                         # the gene side is replicated, identically
+        assert_allclose(p["bes"], st.beta_shape, rtol=tol)
+        assert_allclose(p["ber"], st.beta_rate, rtol=tol)
+        assert_allclose(p["eta_r"], st.eta_rate, rtol=tol)
+        assert_allclose(p["losses"], want_losses, rtol=1e-5 if dtype == np.float32 else 1e-11)
+    assert np.array_equal(parts[0]["bes"], parts[1]["bes"])
