@@ -2,6 +2,7 @@
 // ordering of kernel launches that makes one CAVI iteration (scHPF_.py:657-714).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -10,6 +11,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/schpf_hip.h"
@@ -115,6 +117,7 @@ struct TileDev {
     int64_t n_tasks = 0, entry_slots = 0, n_wave_out = 0;
     int threads = 512;
     size_t lds_bytes = 0;
+    bool packed = false;
 };
 
 struct Profiler {
@@ -292,16 +295,17 @@ template <typename T> struct Engine final : schpf_ctx {
         std::vector<int32_t>().swap(h.slice_steps);
     }
 
-    void build_tile(TileDev &td, int64_t nnz_, const int32_t *major, const int32_t *minor, const float *val,
-                    int n_major, int n_minor, int win_rows, int wpb, int target_tasks)
+    // device half of a tile plan: upload the host-built arrays (td.host), allocate the partials
+    void upload_tile(TileDev &td, double host_seconds)
     {
-        schpf::build_tile_plan(nnz_, major, minor, val, n_major, n_minor, LPC, wpb, win_rows, target_tasks, true,
-                               td.host);
+        const double t1 = now_s();
         auto &h = td.host;
+        const int wpb = h.wpb;
         td.n_tasks = h.n_tasks;
         td.threads = 64 * wpb;
-        td.lds_bytes = (size_t)win_rows * KP * sizeof(T);
-        td.entry_slots = (int64_t)h.entries.size() / 2;
+        td.lds_bytes = (size_t)h.win_rows * KP * sizeof(T);
+        td.entry_slots = (int64_t)h.entries.size() / (h.packed ? 1 : 2);
+        td.packed = h.packed;
         td.n_wave_out = h.n_tasks * wpb;
         upload(td.entries, h.entries, stream);
         upload(td.steps, h.steps, stream);
@@ -315,6 +319,9 @@ template <typename T> struct Engine final : schpf_ctx {
         upload(td.pcount, h.pcount, stream);
         td.partials.alloc((size_t)std::max<int64_t>(h.n_partial_rows, 1) * KP * sizeof(T), true, stream);
         HIPCHK(hipStreamSynchronize(stream));
+        if (env_int("SCHPF_VERBOSE", 0))
+            fprintf(stderr, "[schpf_hip]   tile plan %d x %d: host build %.3f s, H2D %.3f s (%.2f GB entries)\n",
+                    h.n_major, h.n_minor, host_seconds, now_s() - t1, h.entries.size() * 4e-9);
         std::vector<uint32_t>().swap(h.entries);
         std::vector<uint16_t>().swap(h.steps);
         std::vector<int64_t>().swap(h.task_wave_off);
@@ -325,10 +332,10 @@ template <typename T> struct Engine final : schpf_ctx {
     // 152 KiB window (fewest stagings, longest row segments => least sliced-ELL padding).  When
     // that leaves the 256 CUs short of tasks the workgroup is halved (64 KiB windows, two
     // workgroups per CU) until there are enough (block, window) pairs.
-    void build_tile_auto(TileDev &td, const int32_t *major, const int32_t *minor, const float *val, int n_major,
-                         int n_minor)
+    void tile_shape(int n_major, int n_minor, int &wpb, int &win_rows, int &tasks) const
     {
-        int wpb = env_int("SCHPF_WPB", 0), lds_kb = env_int("SCHPF_LDS_KB", 0);
+        wpb = env_int("SCHPF_WPB", 0);
+        int lds_kb = env_int("SCHPF_LDS_KB", 0);
         const size_t row_bytes = (size_t)KP * sizeof(T);
         if (!wpb) {
             wpb = 16;
@@ -342,32 +349,84 @@ template <typename T> struct Engine final : schpf_ctx {
             }
         }
         if (!lds_kb) lds_kb = wpb >= 12 ? 152 : 64;
-        const int win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
-        const int tasks = env_int("SCHPF_TASKS", wpb >= 12 ? 1024 : 2048);
-        build_tile(td, nnz, major, minor, val, n_major, n_minor, win_rows, wpb, tasks);
+        win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
+        tasks = env_int("SCHPF_TASKS", wpb >= 12 ? 1024 : 2048);
+    }
+
+    // both orientations are built concurrently on the host (each with its own thread team),
+    // then uploaded one after the other on the context's stream
+    void build_tiles(const int32_t *row, const int32_t *col, const float *val)
+    {
+        int wpb_c, wr_c, tk_c, wpb_g, wr_g, tk_g;
+        tile_shape(N, G, wpb_c, wr_c, tk_c);
+        tile_shape(G, N, wpb_g, wr_g, tk_g);
+        const bool allow_pack = env_int("SCHPF_PACK", 1) != 0;
+        std::exception_ptr err;
+        double secs_gene = 0.0;
+        std::thread side([&] {
+            try {
+                const double t0 = now_s();
+                schpf::build_tile_plan(nnz, col, row, val, G, N, LPC, wpb_g, wr_g, tk_g, true, allow_pack, tgene.host);
+                secs_gene = now_s() - t0;
+            } catch (...) { err = std::current_exception(); }
+        });
+        double secs_cell = 0.0;
+        try {
+            const double t0 = now_s();
+            schpf::build_tile_plan(nnz, row, col, val, N, G, LPC, wpb_c, wr_c, tk_c, true, allow_pack, tcell.host);
+            secs_cell = now_s() - t0;
+        } catch (...) { side.join(); throw; }
+        side.join();
+        if (err) std::rethrow_exception(err);
+        upload_tile(tcell, secs_cell);
+        upload_tile(tgene, secs_gene);
+    }
+
+    static double now_s()
+    {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
 
     void upload_coo(int64_t nnz_, const int32_t *row, const int32_t *col, const void *val, int kind) override
     {
+        const bool verbose = env_int("SCHPF_VERBOSE", 0) != 0;
+        const double t_start = now_s();
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
         std::vector<float> v((size_t)nnz_);
-        for (int64_t i = 0; i < nnz_; ++i) {
-            double d;
-            switch (kind) {
-            case SCHPF_VAL_I32: d = (double)((const int32_t *)val)[i]; break;
-            case SCHPF_VAL_I64: d = (double)((const int64_t *)val)[i]; break;
-            case SCHPF_VAL_F32: d = (double)((const float *)val)[i]; break;
-            case SCHPF_VAL_F64: d = ((const double *)val)[i]; break;
-            default: throw std::invalid_argument("unknown value kind");
+        {   // validate + convert, in parallel slabs (first offending entry per slab is reported)
+            const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(schpf::host_threads(), nnz_ / 65536 + 1));
+            std::vector<int64_t> bad_val((size_t)nth, -1), bad_idx((size_t)nth, -1);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; ++t)
+                th.emplace_back([&, t] {
+                    const int64_t b = nnz_ * t / nth, e = nnz_ * (t + 1) / nth;
+                    for (int64_t i = b; i < e; ++i) {
+                        double d;
+                        switch (kind) {
+                        case SCHPF_VAL_I32: d = (double)((const int32_t *)val)[i]; break;
+                        case SCHPF_VAL_I64: d = (double)((const int64_t *)val)[i]; break;
+                        case SCHPF_VAL_F32: d = (double)((const float *)val)[i]; break;
+                        default: d = ((const double *)val)[i]; break;
+                        }
+                        const float f = (float)d;
+                        if ((!(d > 0.0) || (double)f != d) && bad_val[(size_t)t] < 0) bad_val[(size_t)t] = i;
+                        if ((row[i] < 0 || row[i] >= N || col[i] < 0 || col[i] >= G) && bad_idx[(size_t)t] < 0)
+                            bad_idx[(size_t)t] = i;
+                        v[(size_t)i] = f;
+                    }
+                });
+            for (auto &x : th) x.join();
+            if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
+            for (int t = 0; t < nth; ++t) {
+                if (bad_idx[(size_t)t] >= 0)
+                    throw std::invalid_argument("COO index out of range at entry " + std::to_string(bad_idx[(size_t)t]));
+                if (bad_val[(size_t)t] >= 0)
+                    throw std::invalid_argument("X.data must be > 0 and exactly representable in float32 "
+                                                "(UMI counts are); offending entry " +
+                                                std::to_string(bad_val[(size_t)t]));
             }
-            const float f = (float)d;
-            if (!(d > 0.0) || (double)f != d)
-                throw std::invalid_argument("X.data must be > 0 and exactly representable in float32 "
-                                            "(UMI counts are); offending entry " + std::to_string(i));
-            if (row[i] < 0 || row[i] >= N || col[i] < 0 || col[i] >= G)
-                throw std::invalid_argument("COO index out of range at entry " + std::to_string(i));
-            v[(size_t)i] = f;
         }
+        const double t_valid = now_s();
         nnz = nnz_;
         const int cpw = 64 / LPC;
         int chunk = env_int("SCHPF_CHUNK", 0);
@@ -383,8 +442,7 @@ template <typename T> struct Engine final : schpf_ctx {
         cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
         int64_t n_out;
         if (use_tile) {
-            build_tile_auto(tcell, row, col, v.data(), N, G);
-            build_tile_auto(tgene, col, row, v.data(), G, N);
+            build_tiles(row, col, v.data());
             n_out = tcell.n_wave_out;
         } else {
             const int wc = pick_windows((size_t)G * KP * sizeof(T), "SCHPF_WINDOWS_CELL");
@@ -395,6 +453,7 @@ template <typename T> struct Engine final : schpf_ctx {
         }
         wave_out.alloc((size_t)std::max<int64_t>(n_out, 1) * sizeof(double), true, stream);
 
+        const double t_plans = now_s();
         // constant term of the loss: sum lgamma(x + 1)   (hpf_numba.py:49-50)
         DevBuf dv, part;
         upload(dv, v, stream);
@@ -407,6 +466,9 @@ template <typename T> struct Engine final : schpf_ctx {
         HIPCHK(hipStreamSynchronize(stream));
         have_coo = true;
         pending_init = 0;
+        if (verbose)
+            fprintf(stderr, "[schpf_hip] upload_coo nnz=%lld: validate %.3f s, plans+H2D %.3f s, gammaln %.3f s (%d host threads)\n",
+                    (long long)nnz, t_valid - t_start, t_plans - t_valid, now_s() - t_plans, schpf::host_threads());
     }
 
     DevBuf &shape_buf(int which)
@@ -512,7 +574,7 @@ template <typename T> struct Engine final : schpf_ctx {
                                  const DevBuf &log_major, const DevBuf &log_minor, int n_minor)
     {
         schpf::TileArgs<T> a{};
-        a.entries = td.entries.as<uint4>();
+        a.entries = td.entries.p;
         a.steps = td.steps.as<uint16_t>();
         a.block_rows = td.block_rows.as<int>();
         a.task_block = td.task_block.as<int>();
@@ -528,6 +590,7 @@ template <typename T> struct Engine final : schpf_ctx {
         a.wave_out = wave_out.as<double>();
         a.K = K; a.n_minor = n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
         a.wpb = td.host.wpb;
+        a.debug = env_int("SCHPF_DEBUG_TILE", 0);
         return a;
     }
 
@@ -543,7 +606,7 @@ template <typename T> struct Engine final : schpf_ctx {
             TileDev &td = cellside ? tcell : tgene;
             auto a = tile_args(td, tmaj, tmin, lmaj, lmin, cellside ? G : N);
             a.seed = seed; a.major_is_cell = cellside ? 1 : 0;
-            HIPCHK(schpf::launch_tile_sweep<T>(a, NV, LPC, mode, td.n_tasks, td.threads, td.lds_bytes, stream));
+            HIPCHK(schpf::launch_tile_sweep<T>(a, NV, LPC, mode, td.packed ? 1 : 0, td.n_tasks, td.threads, td.lds_bytes, stream));
         } else {
             PlanDev &pd = cellside ? cell : gene;
             auto a = sweep_args(pd, tmaj, tmin, lmaj, lmin);
@@ -1058,7 +1121,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
     return guarded([&] {
         schpf::TilePlanHost P;
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, lpc, waves_per_block, win_rows,
-                               target_tasks, false, P);
+                               target_tasks, false, getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
         int64_t n = 0;
         for (int64_t t = 0; t < P.n_tasks; ++t) {
@@ -1070,14 +1133,22 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                     for (int p = 0; p < steps; ++p)
                         for (int grp = 0; grp < gpw; ++grp)
                             for (int u = 0; u < 2; ++u) {
-                                const uint32_t *e = P.entries.data() + ((size_t)off + (size_t)p * gpw + grp) * 4 + (size_t)u * 2;
                                 float f;
-                                std::memcpy(&f, &e[1], 4);
+                                uint32_t local;
+                                if (P.packed) {
+                                    const uint32_t *e = P.entries.data() + ((size_t)off + (size_t)p * gpw + grp) * 2;
+                                    local = (e[0] >> (16 * u)) & 0xFFFFu;
+                                    f = (float)((e[1] >> (16 * u)) & 0xFFFFu);
+                                } else {
+                                    const uint32_t *e = P.entries.data() + ((size_t)off + (size_t)p * gpw + grp) * 4 + (size_t)u * 2;
+                                    local = e[0];
+                                    std::memcpy(&f, &e[1], 4);
+                                }
                                 if (f == 0.0f) continue;
                                 if (n >= nnz) throw std::logic_error("tile plan stores more nonzeros than given");
                                 const int g = v * gpw + grp;
                                 out_major[n] = P.block_rows[(size_t)b * gpb + g];
-                                out_minor[n] = (int32_t)(w * P.win_rows + (int)e[0]);
+                                out_minor[n] = (int32_t)(w * P.win_rows + (int)local);
                                 out_val[n] = f;
                                 out_prow[n] = (int32_t)(t * gpb + g);
                                 out_task[n] = (int32_t)t;
@@ -1090,7 +1161,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         if (n != nnz) throw std::logic_error("tile plan lost nonzeros");
         for (int m = 0; m < n_major; ++m) { out_pfirst[m] = P.pfirst[(size_t)m]; out_pcount[m] = P.pcount[(size_t)m]; }
         stats[0] = P.n_tasks; stats[1] = P.n_blocks; stats[2] = P.n_windows; stats[3] = P.pstride;
-        stats[4] = (int64_t)P.entries.size() / 2; stats[5] = P.windows_per_task;
+        stats[4] = (int64_t)P.entries.size() / (P.packed ? 1 : 2); stats[5] = P.windows_per_task;
     });
 }
 

@@ -27,7 +27,7 @@ template <typename T> struct SweepArgs {
 
 // LDS-staged sweep over a tile plan (plan.h, TilePlanHost)
 template <typename T> struct TileArgs {
-    const uint4 *entries;          // {local0, val0, local1, val1}
+    const void *entries;           // uint4 {local0, val0, local1, val1} or packed uint2 (plan.h)
     const uint16_t *steps;         // [(block * wpb + wave) * n_windows + window]
     const int *block_rows;         // [n_blocks * gpb]
     const int *task_block, *task_w0, *task_w1;
@@ -41,6 +41,7 @@ template <typename T> struct TileArgs {
     int K, n_minor, n_windows, win_rows, wpb;
     uint64_t seed;                 // MODE_RANDOM
     int major_is_cell;
+    int debug;                     // timing experiments only (SCHPF_DEBUG_TILE): 1 = skip staging copy, 2 = skip barriers
 };
 
 template <typename T> struct UpdateArgs {
@@ -67,8 +68,8 @@ template <typename T>
 hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t seed, int major_is_cell,
                              int64_t n_waves, hipStream_t st);
 template <typename T>
-hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int64_t n_tasks, int threads,
-                             size_t lds_bytes, hipStream_t st);
+hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int packed, int64_t n_tasks,
+                             int threads, size_t lds_bytes, hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);

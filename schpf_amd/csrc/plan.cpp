@@ -2,21 +2,79 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 namespace schpf {
+
+// ---- host threading: plan construction is O(nnz) passes with random access; at the headline
+// size (1e8 nonzeros) it would otherwise dominate a whole fit ----
+int host_threads()
+{
+    const char *s = getenv("SCHPF_HOST_THREADS");
+    if (s && *s) return std::max(1, atoi(s));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min<unsigned>(hw ? hw : 1, 32);
+}
+
+// f(begin, end, thread_index) over [0, n) in contiguous slabs
+template <typename F> static void parallel_for(int64_t n, int nth, F f)
+{
+    if (n <= 0) return;
+    nth = (int)std::max<int64_t>(1, std::min<int64_t>(nth, n));
+    if (nth == 1) { f((int64_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nth);
+    for (int t = 0; t < nth; ++t) {
+        const int64_t b = n * t / nth, e = n * (t + 1) / nth;
+        th.emplace_back([=, &f] { f(b, e, t); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// stable parallel counting sort of the sequence seq[0..n) (or 0..n-1 when seq == nullptr) by
+// key[seq[j]]: out[rank] = seq[j]; ptr = run pointers per key
+static void counting_sort_seq(int64_t n, const int32_t *seq, const int32_t *key, int nkeys,
+                              std::vector<int32_t> &out, std::vector<int64_t> &ptr)
+{
+    int nth = host_threads();
+    while (nth > 1 && (int64_t)nth * nkeys > (int64_t)48 << 20) nth /= 2;   // bound the counter table
+    if (n < (1 << 16)) nth = 1;
+    std::vector<uint32_t> counts((size_t)nth * nkeys, 0u);
+    parallel_for(n, nth, [&](int64_t b, int64_t e, int t) {
+        uint32_t *c = counts.data() + (size_t)t * nkeys;
+        for (int64_t j = b; j < e; ++j) c[key[seq ? seq[j] : (int32_t)j]]++;
+    });
+    ptr.assign((size_t)nkeys + 1, 0);
+    std::vector<int64_t> start((size_t)nth * nkeys);
+    int64_t run = 0;
+    for (int k = 0; k < nkeys; ++k) {
+        ptr[(size_t)k] = run;
+        for (int t = 0; t < nth; ++t) {
+            start[(size_t)t * nkeys + k] = run;
+            run += counts[(size_t)t * nkeys + k];
+        }
+    }
+    ptr[(size_t)nkeys] = run;
+    out.resize((size_t)n);
+    parallel_for(n, nth, [&](int64_t b, int64_t e, int t) {
+        int64_t *s = start.data() + (size_t)t * nkeys;
+        for (int64_t j = b; j < e; ++j) {
+            const int32_t pos = seq ? seq[j] : (int32_t)j;
+            out[(size_t)s[key[pos]]++] = pos;
+        }
+    });
+}
 
 void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vector<int32_t> &order,
                              std::vector<int64_t> &ptr)
 {
-    ptr.assign((size_t)nkeys + 1, 0);
-    for (int64_t i = 0; i < n; ++i) ptr[(size_t)key[i] + 1]++;
-    for (int k = 0; k < nkeys; ++k) ptr[(size_t)k + 1] += ptr[k];
-    std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
-    order.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) order[(size_t)cur[key[i]]++] = (int32_t)i;
+    counting_sort_seq(n, nullptr, key, nkeys, order, ptr);
 }
 
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
@@ -25,16 +83,8 @@ void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor
     // minor first, then stable by major
     std::vector<int32_t> by_minor;
     std::vector<int64_t> tmp_ptr;
-    counting_sort_positions(nnz, minor, n_minor, by_minor, tmp_ptr);
-    mptr.assign((size_t)n_major + 1, 0);
-    for (int64_t i = 0; i < nnz; ++i) mptr[(size_t)major[i] + 1]++;
-    for (int m = 0; m < n_major; ++m) mptr[(size_t)m + 1] += mptr[m];
-    order.resize((size_t)nnz);
-    std::vector<int64_t> cur(mptr.begin(), mptr.end() - 1);
-    for (int64_t j = 0; j < nnz; ++j) {
-        const int32_t pos = by_minor[(size_t)j];
-        order[(size_t)cur[major[pos]]++] = pos;
-    }
+    counting_sort_seq(nnz, nullptr, minor, n_minor, by_minor, tmp_ptr);
+    counting_sort_seq(nnz, by_minor.data(), major, n_major, order, mptr);
 }
 
 namespace {
@@ -202,7 +252,7 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                      int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, TilePlanHost &P)
+                     int target_tasks, bool keep_order, bool allow_packed, TilePlanHost &P)
 {
     if (lpc < 1 || lpc > 64 || (64 % lpc) != 0) throw std::invalid_argument("lpc must divide 64");
     if (waves_per_block < 1 || waves_per_block > 16) throw std::invalid_argument("waves_per_block in [1,16]");
@@ -219,9 +269,13 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     P.nnz = nnz;
     const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb;
 
+    const bool verbose = getenv("SCHPF_VERBOSE") && atoi(getenv("SCHPF_VERBOSE"));
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     std::vector<int32_t> order;
     std::vector<int64_t> mptr;
     sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
+    const double t1 = now();
 
     // rows by length, longest first (stable): a wave's groups then carry similar loads
     std::vector<int32_t> rows((size_t)n_major);
@@ -260,22 +314,44 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
             if (row >= 0) P.pfirst[(size_t)row] = (int32_t)(b * gpb + g);
         }
 
-    // per (block, wave, window): steps = ceil(longest segment / 2); then offsets and entries
-    P.steps.assign((size_t)P.n_blocks * wpb * W, 0);
-    std::vector<int32_t> seglen((size_t)W);
-    for (int64_t b = 0; b < P.n_blocks; ++b)
-        for (int g = 0; g < gpb; ++g) {
-            const int32_t row = P.block_rows[(size_t)b * gpb + g];
-            if (row < 0) continue;
-            std::fill(seglen.begin(), seglen.end(), 0);
-            for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) seglen[(size_t)(minor[order[(size_t)j]] / win_rows)]++;
-            uint16_t *st = P.steps.data() + ((size_t)b * wpb + g / gpw) * W;
-            for (int w = 0; w < W; ++w) {
-                const int32_t s = (seglen[(size_t)w] + 1) / 2;   // two nonzeros per step
-                if (s > 65535) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
-                if (s > st[w]) st[w] = (uint16_t)s;
-            }
+    // sorted copies: every later pass walks the rows' runs sequentially
+    const int nth = host_threads();
+    std::vector<int32_t> s_minor((size_t)nnz);
+    std::vector<float> s_val((size_t)nnz);
+    parallel_for(nnz, nth, [&](int64_t b, int64_t e, int) {
+        for (int64_t j = b; j < e; ++j) {
+            const int32_t pos = order[(size_t)j];
+            s_minor[(size_t)j] = minor[pos];
+            s_val[(size_t)j] = val[pos];
         }
+    });
+
+    const double t2 = now();
+    // per (block, wave, window): steps = ceil(longest segment / 2).  Threads own whole blocks.
+    P.steps.assign((size_t)P.n_blocks * wpb * W, 0);
+    std::vector<int> err((size_t)nth + 1, 0);
+    parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int t) {
+        for (int64_t b = b0; b < b1; ++b)
+            for (int g = 0; g < gpb; ++g) {
+                const int32_t row = P.block_rows[(size_t)b * gpb + g];
+                if (row < 0) continue;
+                uint16_t *st = P.steps.data() + ((size_t)b * wpb + g / gpw) * W;
+                int64_t j = mptr[row];
+                const int64_t end = mptr[(size_t)row + 1];
+                while (j < end) {           // runs of equal window (the row is sorted by minor)
+                    const int32_t w = s_minor[(size_t)j] / win_rows;
+                    int64_t s = j;
+                    while (j < end && s_minor[(size_t)j] / win_rows == w) ++j;
+                    const int64_t steps = (j - s + 1) / 2;   // two nonzeros per step
+                    if (steps > 65535) { err[(size_t)t] = 1; continue; }
+                    if (steps > st[w]) st[w] = (uint16_t)steps;
+                }
+            }
+    });
+    for (int e : err)
+        if (e) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
+
+    const double t3 = now();
     std::vector<int64_t> wave_off((size_t)P.n_blocks * wpb + 1, 0);   // entries of (block, wave), window order
     for (size_t bw = 0; bw < (size_t)P.n_blocks * wpb; ++bw) {
         int64_t tot = 0;
@@ -283,41 +359,72 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
         wave_off[bw + 1] = wave_off[bw] + tot * gpw;
     }
     const int64_t total = wave_off.back();
-    P.entries.assign((size_t)total * 4, 0u);
+    // packed entries (8 bytes per step: two 16-bit window-local indices + two 16-bit counts) when
+    // every count fits 16 bits -- UMI counts do; otherwise 16 bytes per step (32-bit index, float)
+    bool packed = allow_packed && win_rows <= 65536;
+    if (packed) {
+        std::vector<int> big((size_t)nth + 1, 0);
+        parallel_for(nnz, nth, [&](int64_t b, int64_t e, int t) {
+            for (int64_t j = b; j < e; ++j) {
+                const float f = s_val[(size_t)j];
+                if (!(f <= 65535.0f) || f != (float)(uint32_t)f) { big[(size_t)t] = 1; break; }
+            }
+        });
+        for (int v : big) packed = packed && !v;
+    }
+    P.packed = packed;
+    const int epw = packed ? 2 : 4;      // 32-bit words per step slot
+    P.entries.resize((size_t)total * epw);
+    parallel_for(total * epw, nth, [&](int64_t b, int64_t e, int) {
+        std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
+    });
     P.task_wave_off.resize((size_t)P.n_tasks * wpb);
     P.task_wave_end.resize((size_t)P.n_tasks * wpb);
-    for (int64_t b = 0; b < P.n_blocks; ++b)
-        for (int v = 0; v < wpb; ++v) {
-            const size_t bw = (size_t)b * wpb + v;
-            int64_t off = wave_off[bw];
-            for (int w = 0; w < W; ++w) {
-                const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
-                if (w % wpt == 0) P.task_wave_off[tv] = off;
-                off += (int64_t)P.steps[bw * W + w] * gpw;
-                P.task_wave_end[tv] = off;
+    // fill: walk each row's nonzeros in minor order; position inside its window segment = t
+    parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
+        std::vector<int64_t> win_off((size_t)W);
+        for (int64_t b = b0; b < b1; ++b) {
+            for (int v = 0; v < wpb; ++v) {
+                const size_t bw = (size_t)b * wpb + v;
+                int64_t off = wave_off[bw];
+                for (int w = 0; w < W; ++w) {
+                    const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
+                    if (w % wpt == 0) P.task_wave_off[tv] = off;
+                    off += (int64_t)P.steps[bw * W + w] * gpw;
+                    P.task_wave_end[tv] = off;
+                }
+            }
+            for (int g = 0; g < gpb; ++g) {
+                const int32_t row = P.block_rows[(size_t)b * gpb + g];
+                if (row < 0) continue;
+                const size_t bw = (size_t)b * wpb + g / gpw;
+                int64_t off = wave_off[bw];
+                for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += (int64_t)P.steps[bw * W + w] * gpw; }
+                const int slot = g % gpw;
+                int32_t cur_w = -1, t = 0;
+                for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) {
+                    const int32_t mn = s_minor[(size_t)j];
+                    const int32_t w = mn / win_rows;
+                    if (w != cur_w) { cur_w = w; t = 0; }
+                    const size_t step_slot = (size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot;
+                    if (packed) {
+                        uint32_t *e = P.entries.data() + step_slot * 2;
+                        const int sh = (t & 1) * 16;
+                        e[0] |= (uint32_t)(mn - w * win_rows) << sh;
+                        e[1] |= (uint32_t)s_val[(size_t)j] << sh;
+                    } else {
+                        uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
+                        e[0] = (uint32_t)(mn - w * win_rows);
+                        e[1] = f2u(s_val[(size_t)j]);
+                    }
+                    ++t;
+                }
             }
         }
-    // fill: walk each row's nonzeros in minor order; position inside its (window) segment = t
-    std::vector<int64_t> win_off((size_t)W);
-    for (int64_t b = 0; b < P.n_blocks; ++b)
-        for (int g = 0; g < gpb; ++g) {
-            const int32_t row = P.block_rows[(size_t)b * gpb + g];
-            if (row < 0) continue;
-            const size_t bw = (size_t)b * wpb + g / gpw;
-            int64_t off = wave_off[bw];
-            for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += (int64_t)P.steps[bw * W + w] * gpw; }
-            const int slot = g % gpw;
-            int32_t cur_w = -1, t = 0;
-            for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) {
-                const int32_t pos = order[(size_t)j];
-                const int32_t w = minor[pos] / win_rows;
-                if (w != cur_w) { cur_w = w; t = 0; }
-                uint32_t *e = P.entries.data() + ((size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot) * 4 + (size_t)(t & 1) * 2;
-                e[0] = (uint32_t)(minor[pos] - w * win_rows);
-                e[1] = f2u(val[pos]);
-                ++t;
-            }
-        }
+    });
+    if (verbose)
+        fprintf(stderr, "[schpf_hip]     sort %.3f s, sorted copies %.3f s, steps %.3f s, alloc+fill %.3f s\n", t1 - t0,
+                t2 - t1, t3 - t2, now() - t3);
     if (keep_order) {
         P.order.swap(order);
         P.mptr.swap(mptr);

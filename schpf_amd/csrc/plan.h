@@ -66,8 +66,10 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 // minor K-vectors from LDS.  A row's accumulators stay in registers for the whole task, so one
 // partial K-vector per (row, task) leaves the kernel.
 //
-//   entries   sliced-ELL per (block, wave, window): step-major uint4 {local0, val0, local1,
-//             val1} for the gpw groups of the wave; local = minor - window * win_rows
+//   entries   sliced-ELL per (block, wave, window): step-major, one slot per group of the wave
+//             holding two nonzeros: uint4 {local0, val0, local1, val1} or, when all counts fit
+//             16 bits, packed uint2 {local0 | local1 << 16, cnt0 | cnt1 << 16};
+//             local = minor - window * win_rows
 //   steps     [ (block * wpb + wave) * n_windows + window ]  uint16 steps of that sub-slice
 //   task_*    block, first window, end window of each task; tasks are ordered window-range
 //             major / block minor so that concurrently running workgroups stage the same slice
@@ -80,6 +82,7 @@ struct TilePlanHost {
     int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
     int win_rows = 0, n_windows = 0, windows_per_task = 0;
     int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
+    bool packed = false;                  // 8-byte entries {idx0|idx1<<16, cnt0|cnt1<<16} instead of 16-byte
     std::vector<uint32_t> entries;
     std::vector<uint16_t> steps;
     std::vector<int32_t> block_rows;      // [n_blocks * gpb] major id or -1
@@ -92,11 +95,14 @@ struct TilePlanHost {
 
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                      int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, TilePlanHost &out);
+                     int target_tasks, bool keep_order, bool allow_packed, TilePlanHost &out);
 
 // positions sorted by (major, minor) and the per-major run pointers
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
                          std::vector<int32_t> &order, std::vector<int64_t> &mptr);
+
+// number of host threads used by the builders ($SCHPF_HOST_THREADS, default min(cores, 32))
+int host_threads();
 
 // Stable counting sort of positions by key: order[j] = original position of the j-th
 // smallest key; ptr[k]..ptr[k+1] is the run of key k.

@@ -132,6 +132,17 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
+
+// x / s without a branch: padding entries carry x = 0 (weight 0); an underflowed normaliser
+// (ok == false) is divided as 1 and masked -- the cold path redoes that group afterwards.
+template <typename T> __device__ __forceinline__ T safe_weight(T x, T s, bool ok)
+{
+    const T q = fast_div(x, ok ? s : T(1));
+    return ok ? q : T(0);
+}
+
 // s = sum_k a_k b_k over the whole group (every lane of the group gets the same value)
 template <typename T, int KL, int LPC>
 __device__ __forceinline__ T group_dot(const T (&x)[KL], const T (&y)[KL])
@@ -213,11 +224,13 @@ __device__ __noinline__ void slow_chunk(const uint4 *__restrict__ ep, int steps,
     store_lane<T, NV, LPC>(out_row, sub, acc);
 }
 // ... and for the tile plan: a row's nonzeros over the windows [w0, w1) of its task
-template <typename T, int NV, int LPC>
-__device__ __noinline__ void slow_task_row(const uint4 *__restrict__ ep, const uint16_t *__restrict__ st, int w0,
-                                           int w1, int win_rows, int stride, const T *__restrict__ lt_row,
+template <bool PACK> struct TileEntry;
+template <typename T, int NV, int LPC, bool PACK>
+__device__ __noinline__ void slow_task_row(const void *__restrict__ entries, size_t pos, const uint16_t *__restrict__ st,
+                                           int w0, int w1, int win_rows, int stride, const T *__restrict__ lt_row,
                                            const T *__restrict__ log_minor, int sub, int K, T *__restrict__ out_row)
 {
+    typedef TileEntry<PACK> EF;
     constexpr int KL = NV * Vec16<T>::N;
     constexpr int KP = KL * LPC;
     T acc[KL];
@@ -229,13 +242,14 @@ __device__ __noinline__ void slow_task_row(const uint4 *__restrict__ ep, const u
         const T *__restrict__ lm = log_minor + (size_t)w * win_rows * KP;
 #pragma unroll 1
         for (int p = 0; p < steps; ++p) {
-            const uint4 ee = ep[(size_t)p * stride];
-            if (__uint_as_float(ee.y) > 0.f)
-                slow_nonzero<T, NV, LPC>(lt_row, lm + (size_t)ee.x * KP, sub, K, (T)__uint_as_float(ee.y), acc);
-            if (__uint_as_float(ee.w) > 0.f)
-                slow_nonzero<T, NV, LPC>(lt_row, lm + (size_t)ee.z * KP, sub, K, (T)__uint_as_float(ee.w), acc);
+            const typename EF::type ee = EF::load(entries, pos + (size_t)p * stride);
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const float x = EF::val(ee, u);
+                if (x > 0.f) slow_nonzero<T, NV, LPC>(lt_row, lm + (size_t)EF::idx(ee, u) * KP, sub, K, (T)x, acc);
+            }
         }
-        ep += (size_t)steps * stride;
+        pos += (size_t)steps * stride;
     }
     store_lane<T, NV, LPC>(out_row, sub, acc);
 }
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs<T> a)
     bool any_bad = false;
 
     const uint4 *__restrict__ ep = a.entries + a.slice_off[slice] + slot;
-    const int steps = a.slice_steps[slice];
+    const int steps = __builtin_amdgcn_readfirstlane(a.slice_steps[slice]);
     const T *__restrict__ tabm = a.tab_minor;
     const T tiny = Vec16<T>::tiny();
 
@@ -290,11 +304,10 @@ __global__ __launch_bounds__(256) void sweep_kernel(SweepArgs<T> a)
         const T s1 = group_dot<T, KL, LPC>(tm, b1);
         if (MODE == MODE_PHI) {
             const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;   // false for NaN too
-            const T w0 = (x0 > T(0) && ok0) ? fast_div(x0, s0) : T(0);
-            const T w1 = (x1 > T(0) && ok1) ? fast_div(x1, s1) : T(0);
+            const T w0 = safe_weight(x0, s0, ok0), w1 = safe_weight(x1, s1, ok1);
             any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
 #pragma unroll
-            for (int k = 0; k < KL; ++k) acc[k] += w0 * b0[k] + w1 * b1[k];
+            for (int k = 0; k < KL; ++k) acc[k] = fma_t(w1, b1[k], fma_t(w0, b0[k], acc[k]));
         } else {
             if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
             if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
@@ -390,26 +403,54 @@ __global__ __launch_bounds__(256) void random_phi_sweep_kernel(SweepArgs<T> a, u
 
 
 // ------------------------------------------------------------- the LDS-staged sweep
+// Entry formats of the tile plan (plan.h): two nonzeros per step slot.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool PACK> struct TileEntry;
+template <> struct TileEntry<true> {      // {idx0 | idx1 << 16, cnt0 | cnt1 << 16}
+    typedef uint2 type;
+    static __device__ __forceinline__ uint2 load(const void *base, size_t i)
+    {
+        const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(base) + i);
+        return make_uint2(v.x, v.y);
+    }
+    static __device__ __forceinline__ unsigned idx(const uint2 &e, int u) { return u ? e.x >> 16 : e.x & 0xFFFFu; }
+    static __device__ __forceinline__ float val(const uint2 &e, int u) { return (float)(u ? e.y >> 16 : e.y & 0xFFFFu); }
+};
+template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
+    typedef uint4 type;
+    static __device__ __forceinline__ uint4 load(const void *base, size_t i)
+    {
+        return stream_load(reinterpret_cast<const uint4 *>(base) + i);
+    }
+    static __device__ __forceinline__ unsigned idx(const uint4 &e, int u) { return u ? e.z : e.x; }
+    static __device__ __forceinline__ float val(const uint4 &e, int u) { return __uint_as_float(u ? e.w : e.y); }
+};
+
 // One workgroup = one task of a tile plan (plan.h): a block of major rows (one per lane
 // group) x a range of minor windows.  Per window: the window's slice of the minor table is
 // copied HBM/L2 -> LDS once (coalesced 16-byte lanes), then every group streams its row's
 // nonzeros of that window (sliced-ELL, coalesced, non-temporal) and gathers the minor
-// K-vectors from LDS with ds_read_b128 -- no per-nonzero L2->L1 line fills.  Two workgroups
-// share a CU (<= 64 KiB LDS each): one stages while the other computes.
-template <typename T, int NV, int LPC, int MODE, int MAXT>
+// K-vectors from LDS with ds_read_b128 -- no per-nonzero L2->L1 line fills.
+// The entry stream runs through a 4-slot register ring: slot i is refilled with step p+4 as
+// soon as step p has been taken out of it, and the ring for the NEXT window is primed before
+// that window's staging barrier, so HBM latency hides behind four steps of math or a staging.
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
     typedef typename Vec16<T>::type V;
+    typedef TileEntry<PACK> EF;
+    typedef typename EF::type E;
     constexpr int VEC = Vec16<T>::N;
     constexpr int KL = NV * VEC;
     constexpr int GPW = 64 / LPC;
     constexpr int KP = KL * LPC;
+    constexpr int RING = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *win = reinterpret_cast<T *>(lds_raw);
 
     const int task = blockIdx.x;
     const int blk = a.task_block[task], w0 = a.task_w0[task], w1 = a.task_w1[task];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int grp = lane / LPC, sub = lane % LPC;
     const int gpb = GPW * a.wpb;
     const int g = wv * GPW + grp;
@@ -424,93 +465,107 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
     bool any_bad = false;
     const T tiny = Vec16<T>::tiny();
 
-    const uint4 *__restrict__ ep = a.entries + a.task_wave_off[(size_t)task * a.wpb + wv] + grp;
+    // position (in step slots) of this group's entries; advances window by window
+    size_t pos = (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp;
     const uint16_t *__restrict__ st = a.steps + ((size_t)blk * a.wpb + wv) * a.n_windows;
 
+    E ring[RING];
+    int steps = __builtin_amdgcn_readfirstlane((int)st[w0]);
+#pragma unroll
+    for (int i = 0; i < RING; ++i)
+        if (i < steps) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
+
     for (int w = w0; w < w1; ++w) {
-        const int steps = st[w];
         if (MODE != MODE_RANDOM) {
-            __syncthreads();                       // previous window fully consumed
+            if (!(a.debug & 2) || w == w0) __syncthreads();   // previous window fully consumed
             const int r0 = w * a.win_rows;
             const int nr = min(a.win_rows, a.n_minor - r0);
             const V *__restrict__ src = reinterpret_cast<const V *>(a.tab_minor + (size_t)r0 * KP);
             V *dst = reinterpret_cast<V *>(win);
-            const int nvec = nr * (KP / VEC);
+            const int nvec = ((a.debug & 1) && w != w0) ? 0 : nr * (KP / VEC);   // debug: stage the first window only
             for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
-            __syncthreads();
+            if (!(a.debug & 2) || w == w0) __syncthreads();
         }
-        if (MODE == MODE_RANDOM) {
-            // t = 0 responsibilities (reference scHPF_.py:652-655) from the counter-based generator
-            for (int p = 0; p < steps; ++p) {
-                const uint4 e = ep[(size_t)p * GPW];
+        for (int p = 0; p < steps; p += RING) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) {
+                if (p + i < steps) {                                   // scalar branch
+                    const E c = ring[i];
+                    if (p + i + RING < steps) ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
+                    if (MODE == MODE_RANDOM) {
+                        // t = 0 responsibilities (reference scHPF_.py:652-655), counter-based draws
 #pragma unroll 1
-                for (int u = 0; u < 2; ++u) {
-                    const unsigned minor = (unsigned)(w * a.win_rows) + (u ? e.z : e.x);
-                    const double x = (double)__uint_as_float(u ? e.w : e.y);
-                    if (!(x > 0.0)) continue;
-                    const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
-                    const uint64_t gene = a.major_is_cell ? (uint64_t)minor : (uint64_t)major;
-                    double d[KL];
-                    double s = 0.0;
+                        for (int u = 0; u < 2; ++u) {
+                            const unsigned minor = (unsigned)(w * a.win_rows) + EF::idx(c, u);
+                            const double x = (double)EF::val(c, u);
+                            if (!(x > 0.0)) continue;
+                            const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
+                            const uint64_t gene = a.major_is_cell ? (uint64_t)minor : (uint64_t)major;
+                            double d[KL];
+                            double s = 0.0;
 #pragma unroll
-                    for (int k = 0; k < KL; ++k) {
-                        const int f = factor_of<T, LPC>(k, sub);
-                        d[k] = f < a.K ? exp1_draw(a.seed, cell, gene, (unsigned)f) : 0.0;
-                        s += d[k];
-                    }
-                    s = group_sum<double, LPC>(s);
-                    const double wgt = x / s;
+                            for (int k = 0; k < KL; ++k) {
+                                const int f = factor_of<T, LPC>(k, sub);
+                                d[k] = f < a.K ? exp1_draw(a.seed, cell, gene, (unsigned)f) : 0.0;
+                                s += d[k];
+                            }
+                            s = group_sum<double, LPC>(s);
+                            const double wgt = x / s;
 #pragma unroll
-                    for (int k = 0; k < KL; ++k) acc[k] += (T)(wgt * d[k]);
-                }
-            }
-        } else if (steps > 0) {
-            // wide rows: one nonzero in flight at a time keeps the register budget (b once)
-            constexpr bool PAIR = KL * (int)sizeof(T) <= 96;
-            uint4 e = stream_load(ep);
-            for (int p = 0; p < steps; ++p) {
-                const uint4 c = e;
-                if (p + 1 < steps) e = stream_load(ep + (size_t)(p + 1) * GPW);
-                if (PAIR) {
-                    T b0[KL], b1[KL];
-                    load_lane<T, NV, LPC>(win + (size_t)c.x * KP, sub, b0);
-                    load_lane<T, NV, LPC>(win + (size_t)c.z * KP, sub, b1);
-                    const T x0 = (T)__uint_as_float(c.y);
-                    const T x1 = (T)__uint_as_float(c.w);
-                    const T s0 = group_dot<T, KL, LPC>(tm, b0);
-                    const T s1 = group_dot<T, KL, LPC>(tm, b1);
-                    if (MODE == MODE_PHI) {
-                        const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;
-                        const T q0 = (x0 > T(0) && ok0) ? fast_div(x0, s0) : T(0);
-                        const T q1 = (x1 > T(0) && ok1) ? fast_div(x1, s1) : T(0);
-                        any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
-#pragma unroll
-                        for (int k = 0; k < KL; ++k) acc[k] += q0 * b0[k] + q1 * b1[k];
+                            for (int k = 0; k < KL; ++k) acc[k] += (T)(wgt * d[k]);
+                        }
                     } else {
-                        if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
-                        if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
-                    }
-                } else {
-#pragma unroll 1
-                    for (int u = 0; u < 2; ++u) {
-                        T b[KL];
-                        load_lane<T, NV, LPC>(win + (size_t)(u ? c.z : c.x) * KP, sub, b);
-                        const T x = (T)__uint_as_float(u ? c.w : c.y);
-                        const T s = group_dot<T, KL, LPC>(tm, b);
-                        if (MODE == MODE_PHI) {
-                            const bool ok = s >= tiny;
-                            const T q = (x > T(0) && ok) ? fast_div(x, s) : T(0);
-                            any_bad |= x > T(0) && !ok;
+                        // narrow rows: both nonzeros of the step in flight; wide rows: one at a time
+                        constexpr bool PAIR = KL * (int)sizeof(T) <= 96;
+                        if (PAIR) {
+                            T b0[KL], b1[KL];
+                            load_lane<T, NV, LPC>(win + (size_t)EF::idx(c, 0) * KP, sub, b0);
+                            load_lane<T, NV, LPC>(win + (size_t)EF::idx(c, 1) * KP, sub, b1);
+                            const T x0 = (T)EF::val(c, 0), x1 = (T)EF::val(c, 1);
+                            const T s0 = group_dot<T, KL, LPC>(tm, b0);
+                            const T s1 = group_dot<T, KL, LPC>(tm, b1);
+                            if (MODE == MODE_PHI) {
+                                const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;
+                                const T q0 = safe_weight(x0, s0, ok0), q1 = safe_weight(x1, s1, ok1);
+                                any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
 #pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] += q * b[k];
+                                for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, b1[k], fma_t(q0, b0[k], acc[k]));
+                            } else {
+                                if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
+                                if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
+                            }
                         } else {
-                            if (x > T(0)) llh += (double)x * log((double)s) - (double)s;
+#pragma unroll 1
+                            for (int u = 0; u < 2; ++u) {
+                                T b[KL];
+                                load_lane<T, NV, LPC>(win + (size_t)EF::idx(c, u) * KP, sub, b);
+                                const T x = (T)EF::val(c, u);
+                                const T s = group_dot<T, KL, LPC>(tm, b);
+                                if (MODE == MODE_PHI) {
+                                    const bool ok = s >= tiny;
+                                    const T q = safe_weight(x, s, ok);
+                                    any_bad |= x > T(0) && !ok;
+#pragma unroll
+                                    for (int k = 0; k < KL; ++k) acc[k] = fma_t(q, b[k], acc[k]);
+                                } else {
+                                    if (x > T(0)) llh += (double)x * log((double)s) - (double)s;
+                                }
+                            }
                         }
                     }
+                    // keep the steps apart: without this fence the compiler hoists every LDS row
+                    // load of the unrolled ring to the top and spills
+                    asm volatile("" ::: "memory");
                 }
             }
         }
-        ep += (size_t)steps * GPW;
+        pos += (size_t)steps * GPW;
+        if (w + 1 < w1) {   // prime the ring for the next window before its staging barrier
+            steps = __builtin_amdgcn_readfirstlane((int)st[w + 1]);
+#pragma unroll
+            for (int i = 0; i < RING; ++i)
+                if (i < steps) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
+        }
     }
 
     if (MODE == MODE_LLH) {
@@ -521,8 +576,8 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
     }
     T *out_row = a.partials + ((size_t)task * gpb + g) * KP;
     if (MODE == MODE_PHI && __builtin_expect(any_bad, 0)) {   // group-uniform; rare: see slow_nonzero
-        slow_task_row<T, NV, LPC>(a.entries + a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
-                                  a.win_rows, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K, out_row);
+        slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
+                                        a.win_rows, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K, out_row);
         return;
     }
     if (MODE == MODE_PHI) {
@@ -533,7 +588,7 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
     store_lane<T, NV, LPC>(out_row, sub, acc);
 }
 
-template <typename T, int NV, int LPC, int MAXT>
+template <typename T, int NV, int LPC, int MAXT, bool PACK>
 static hipError_t launch_tile_b(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
 {
@@ -541,32 +596,34 @@ static hipError_t launch_tile_b(const TileArgs<T> &a, int mode, int64_t n_tasks,
     if (lds_bytes > 64 * 1024) {   // opt in to the full 160 KiB of a CU, once per instantiation
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT>,
+            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT>,
+                e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
     if (mode == MODE_PHI)
-        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT>), grid, block, lds_bytes, st, a);
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>), grid, block, lds_bytes, st, a);
     else if (mode == MODE_LLH)
-        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT>), grid, block, lds_bytes, st, a);
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>), grid, block, lds_bytes, st, a);
     else
-        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_RANDOM, MAXT>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_RANDOM, MAXT, PACK>), grid, block, 0, st, a);
     return hipGetLastError();
 }
-// the launch bound caps the register budget: 1024 threads -> 128 VGPRs, 768 -> 168, 512 -> 256
+// the launch bound caps the register budget: 1024 threads -> 128 VGPRs, 512 -> 256
 template <typename T, int NV, int LPC>
-static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
-                                hipStream_t st)
+static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int64_t n_tasks, int threads,
+                                size_t lds_bytes, hipStream_t st)
 {
     if (n_tasks == 0) return hipSuccess;
-    if (threads <= 512) return launch_tile_b<T, NV, LPC, 512>(a, mode, n_tasks, threads, lds_bytes, st);
-    if (threads <= 768) return launch_tile_b<T, NV, LPC, 768>(a, mode, n_tasks, threads, lds_bytes, st);
-    return launch_tile_b<T, NV, LPC, 1024>(a, mode, n_tasks, threads, lds_bytes, st);
+    if (threads <= 512)
+        return packed ? launch_tile_b<T, NV, LPC, 512, true>(a, mode, n_tasks, threads, lds_bytes, st)
+                      : launch_tile_b<T, NV, LPC, 512, false>(a, mode, n_tasks, threads, lds_bytes, st);
+    return packed ? launch_tile_b<T, NV, LPC, 1024, true>(a, mode, n_tasks, threads, lds_bytes, st)
+                  : launch_tile_b<T, NV, LPC, 1024, false>(a, mode, n_tasks, threads, lds_bytes, st);
 }
 
 // ------------------------------------------------------------------------ launchers
@@ -626,10 +683,10 @@ hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t se
     SCHPF_DISPATCH(nv, lpc, (launch_random_t<T, NV, LPC>(a, seed, major_is_cell, n_waves, st)))
 }
 template <typename T>
-hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int64_t n_tasks, int threads,
-                             size_t lds_bytes, hipStream_t st)
+hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int packed, int64_t n_tasks,
+                             int threads, size_t lds_bytes, hipStream_t st)
 {
-    SCHPF_DISPATCH(nv, lpc, (launch_tile_t<T, NV, LPC>(a, mode, n_tasks, threads, lds_bytes, st)))
+    SCHPF_DISPATCH(nv, lpc, (launch_tile_t<T, NV, LPC>(a, mode, packed, n_tasks, threads, lds_bytes, st)))
 }
 
 }  // namespace schpf
