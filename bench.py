@@ -52,6 +52,47 @@ def synthetic_block(ncells, ngenes, density, seed):
     return X
 
 
+def planted_block(ncells, ngenes, K, target_events, seed):
+    """Generator B of SURVEY.md 8(d): counts from a planted Gamma-Poisson factor model, so that
+    the reference's stop rule has something to converge to.  x_ig ~ Poisson(sum_k theta_ik
+    beta_gk) is sampled factor by factor: the events of factor k are Poisson(S_theta_k *
+    S_beta_k) many, each landing on cell i with probability theta_ik / S_theta_k and gene g with
+    probability beta_gk / S_beta_k (independent because the rate factorises)."""
+    rng = np.random.RandomState(seed)
+    theta = rng.gamma(0.3, 1.0, (ncells, K)) * rng.gamma(2.0, 0.5, (ncells, 1))
+    beta = rng.gamma(0.3, 1.0, (ngenes, K)) * rng.gamma(2.0, 0.5, (ngenes, 1))
+    st, sb = theta.sum(0), beta.sum(0)
+    scale = target_events / float((st * sb).sum())
+    rows, cols = [], []
+    for k in range(K):
+        n_k = rng.poisson(st[k] * sb[k] * scale)
+        rows.append(np.searchsorted(np.cumsum(theta[:, k]) / st[k], rng.random_sample(n_k)).astype(np.int32))
+        cols.append(np.searchsorted(np.cumsum(beta[:, k]) / sb[k], rng.random_sample(n_k)).astype(np.int32))
+    row = np.minimum(np.concatenate(rows), ncells - 1)
+    col = np.minimum(np.concatenate(cols), ngenes - 1)
+    X = coo_matrix((np.ones(row.shape[0], np.int32), (row, col)), shape=(ncells, ngenes), dtype=np.int32)
+    X.sum_duplicates()
+    return X
+
+
+def convergence_run(N, G, K, dtype, density):
+    """Wall-clock of a whole scHPF.fit() under the reference's default stop rule (min 30 / max
+    1000 iterations, loss every 10, epsilon 0.001 %; scHPF_.py:234-238, 750-761) on planted data,
+    host COO in, fitted model out: upload + plan build + iterations + loss checks + download."""
+    from schpf import scHPF
+    X = planted_block(N, G, K, target_events=int(N * G * density * 1.6), seed=42)
+    np.random.seed(0)
+    model = scHPF(K, dtype=dtype, verbose=False)
+    t0 = time.perf_counter()
+    model.fit(X, init="device")
+    wall = time.perf_counter() - t0
+    checks = len(model.loss)
+    return {"data": "planted Gamma-Poisson, %d x %d, nnz %d (density %.4f), max count %d"
+                    % (N, G, X.nnz, X.nnz / float(N) / G, int(X.data.max())),
+            "fit_wall_s": wall, "loss_checks": checks, "iterations": (checks - 1) * model.check_freq + 1,
+            "first_loss": float(model.loss[0]), "final_loss": float(model.loss[-1])}
+
+
 def algorithmic_bytes(nnz, N, G, K, itemsize):
     """B_iter = 12*nnz + 4*K*s*(N+G) + 2*s*(N+G)."""
     return 12 * nnz + 4 * K * itemsize * (N + G) + 2 * itemsize * (N + G)
@@ -117,6 +158,8 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--converge", action="store_true",
+                    help="also time a whole fit() to convergence on planted data (N=1 only, adds minutes)")
     args = ap.parse_args()
 
     import torch
@@ -231,6 +274,9 @@ def main():
         "iterations_per_s_with_loss_every_10": 10.0 / (10 * ms_per_step * 1e-3 + loss_ms * 1e-3),
         "upload_and_plan_s": upload_s,
     }
+    if rank == 0 and world == 1 and args.converge:
+        eng.close()
+        out["convergence"] = convergence_run(N, G, K, dtype, density)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(X, K, dtype)
     elif rank == 0:

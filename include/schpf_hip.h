@@ -47,6 +47,8 @@ extern "C" {
 /* step flags (keyword arguments of scHPF._fit, scHPF_.py:526-530) */
 #define SCHPF_FREEZE_GENES 1u   /* freeze_genes=True: skip the eta/beta block (project()) */
 #define SCHPF_SIMULTANEOUS 2u   /* beta_theta_simultaneous=True (scHPF_.py:666-685)      */
+#define SCHPF_CELLS_FIRST 8u    /* minibatch order (scHPF_.py:688-704): xi/theta block first (theta.rate
+                                   from the current beta), then the gene block from the NEW theta    */
 #define SCHPF_SHARDED 4u        /* cells are sharded over several GPUs: gene-side sums go
                                    through the exchange buffer (all-reduced by the host) */
 

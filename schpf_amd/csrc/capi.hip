@@ -710,6 +710,8 @@ template <typename T> struct Engine final : schpf_ctx {
         ScopedTimer tm(prof, stream, 3);
         // sharded: the all-reduced sum_i E[theta_ik] (old theta) is the tail of the exchange buffer
         if (sharded) widen_tail();
+        const bool cells_first = flags_ & SCHPF_CELLS_FIRST;
+        auto gene_update = [&] {
         if (!freeze) {  // gene block, scHPF_.py:697-704 (or :668-673 + :682-685)
             schpf::UpdateArgs<T> u{};
             u.n = G; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
@@ -728,6 +730,8 @@ template <typename T> struct Engine final : schpf_ctx {
             HIPCHK(schpf::launch_colsum_reduce(colpart_gene.as<double>(), nb, K, s_beta_next.as<double>(), nullptr,
                                                0, stream));
         }
+        };
+        auto cell_update = [&] {
         {  // cell block, scHPF_.py:706-714 (or :675-680)
             schpf::UpdateArgs<T> u{};
             u.n = N; u.K = K; u.KP = KP; u.rows_per_block = rows_per_block();
@@ -738,7 +742,7 @@ template <typename T> struct Engine final : schpf_ctx {
             u.cap_shape = xi_s.as<T>(); u.cap_rate = xi_r.as<T>();
             // theta.rate uses the beta just updated (scHPF_.py:711-713) unless the updates are
             // simultaneous (:677-679) or the genes are frozen
-            u.s_other = (freeze || simultaneous) ? s_beta.as<double>() : s_beta_next.as<double>();
+            u.s_other = (freeze || simultaneous || cells_first) ? s_beta.as<double>() : s_beta_next.as<double>();
             u.cap_prior_rate = bp;
             u.shape = th_s.as<T>(); u.rate = th_r.as<T>(); u.cap_rate_out = xi_r.as<T>();
             u.tab_e = th_e.as<T>(); u.tab_log = th_log.as<T>(); u.tab_exp = th_exp.as<T>();
@@ -748,6 +752,9 @@ template <typename T> struct Engine final : schpf_ctx {
             HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
                                                exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
         }
+        };
+        if (cells_first) { cell_update(); gene_update(); }   // minibatch order: theta first, beta from the NEW theta
+        else { gene_update(); cell_update(); }
         if (!freeze) std::swap(s_beta.p, s_beta_next.p);
         if (pending_init == 1) dense_cell.release();
         pending_init = 0;

@@ -134,36 +134,35 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
     if (t < K) a.colsum_part[(size_t)blockIdx.x * K + t] = sC[t];
 }
 
-// colsum_part [nblocks, K] -> out[K] (double), fixed order.
+// colsum_part [nblocks, K] -> out[K] (double), fixed order.  One workgroup per factor: every
+// thread has its (few) loads in flight at once, then a fixed-shape tree in LDS -- one memory
+// round trip instead of a serial walk over the blocks.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double *__restrict__ part, int nblocks,
                                                              int K, double *__restrict__ out,
                                                              void *mirror, int mirror_is_f32)
 {
     __shared__ double red[256];
-    const int t = threadIdx.x;
-    const int lanes = 256 / K;          // partial accumulators per factor
-    const int k = t % K, j = t / K;
-    double s = 0.0;
-    if (j < lanes) {
-        double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int b = j;
-        for (; b + 3 * lanes < nblocks; b += 4 * lanes) {     // four loads in flight, fixed order
-            const double v0 = part[(size_t)b * K + k], v1 = part[(size_t)(b + lanes) * K + k];
-            const double v2 = part[(size_t)(b + 2 * lanes) * K + k], v3 = part[(size_t)(b + 3 * lanes) * K + k];
-            s += v0; s1 += v1; s2 += v2; s3 += v3;
-        }
-        for (; b < nblocks; b += lanes) s += part[(size_t)b * K + k];
-        s = (s + s1) + (s2 + s3);
+    const int t = threadIdx.x, k = blockIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = t;
+    for (; b + 768 < nblocks; b += 1024) {
+        const double v0 = part[(size_t)b * K + k], v1 = part[(size_t)(b + 256) * K + k];
+        const double v2 = part[(size_t)(b + 512) * K + k], v3 = part[(size_t)(b + 768) * K + k];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    red[t] = s;
+    for (; b < nblocks; b += 256) s0 += part[(size_t)b * K + k];
+    red[t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (t < K) {
-        double tot = 0.0;
-        for (int q = 0; q < lanes; ++q) tot += red[q * K + t];
-        out[t] = tot;
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (t < m) red[t] += red[t + m];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double tot = red[0];
+        out[k] = tot;
         if (mirror) {
-            if (mirror_is_f32) ((float *)mirror)[t] = (float)tot;
-            else ((double *)mirror)[t] = tot;
+            if (mirror_is_f32) ((float *)mirror)[k] = (float)tot;
+            else ((double *)mirror)[k] = tot;
         }
     }
 }
@@ -406,7 +405,7 @@ template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st)
 {
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(1), dim3(256), 0, st, part, nblocks, K, out, mirror,
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)K), dim3(256), 0, st, part, nblocks, K, out, mirror,
                        mirror_is_f32);
     return hipGetLastError();
 }

@@ -122,12 +122,15 @@ class DeviceCAVI(object):
         _lib.check(self._lib.schpf_init_phi_device(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1))))
 
     @staticmethod
-    def _flags(freeze_genes, simultaneous, sharded=False):
+    def _flags(freeze_genes, simultaneous, sharded=False, cells_first=False):
         return ((_lib.FREEZE_GENES if freeze_genes else 0) | (_lib.SIMULTANEOUS if simultaneous else 0)
-                | (_lib.SHARDED if sharded else 0))
+                | (_lib.SHARDED if sharded else 0) | (_lib.CELLS_FIRST if cells_first else 0))
 
-    def step(self, freeze_genes=False, simultaneous=False):
-        _lib.check(self._lib.schpf_step(self._h, self._flags(freeze_genes, simultaneous)))
+    def step(self, freeze_genes=False, simultaneous=False, cells_first=False):
+        """One CAVI iteration.  cells_first=True is the reference's minibatch order
+        (scHPF_.py:688-704): cell block from the current beta, then gene block from the new theta."""
+        _lib.check(self._lib.schpf_step(self._h, self._flags(freeze_genes, simultaneous,
+                                                             cells_first=cells_first)))
 
     def step_local(self, freeze_genes=False, simultaneous=False):
         _lib.check(self._lib.schpf_step_local(self._h, self._flags(freeze_genes, simultaneous, True)))

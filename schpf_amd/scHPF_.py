@@ -277,7 +277,7 @@ class scHPF(BaseEstimator):
     def _fit(self, X, freeze_genes=False, reinit=True, loss_function=None, min_iter=None,
              max_iter=None, epsilon=None, check_freq=None, single_process=False,
              checkstep_function=None, verbose=None, batchsize=None,
-             beta_theta_simultaneous=False, loss_smoothing=1, device=None, init="auto"):
+             beta_theta_simultaneous=False, loss_smoothing=1, device=None, init="auto", engine=None):
         """The CAVI loop (scHPF_.py:526-780) on the GPU.
 
         Keyword arguments are the reference's.  `single_process` is accepted and
@@ -285,15 +285,17 @@ class scHPF(BaseEstimator):
         `device` (HIP device ordinal, default $SCHPF_DEVICE or 0) and `init`
         ('numpy': t=0 responsibilities drawn with the NumPy global RNG exactly like
         the reference; 'device': drawn on the GPU; 'auto': numpy unless nnz*K is
-        beyond what a host draw can reasonably do).
+        beyond what a host draw can reasonably do); `engine`, a DeviceCAVI that already holds
+        X (run_trials reuses one upload for all restarts).
+        `batchsize` (minibatch CAVI, scHPF_.py:626-650, 688-695) runs every iteration on the
+        device too, but re-uploads the batch's rows each iteration like the reference re-slices
+        them -- it exists for behavioural parity, not speed (nothing in HBM-sized data needs it).
         Returns (bp, dp, xi, eta, theta, beta, loss) like the reference.
         """
         assert loss_smoothing > 0
-        if batchsize is not None and 1 < batchsize <= X.shape[0]:
-            raise NotImplementedError(
-                "minibatch CAVI (batchsize) is not on the device path yet; pass batchsize=None/0")
         if not hasattr(X, "row"):
             X = X.tocoo()
+        batched = batchsize is not None and 1 < batchsize <= X.shape[0]
         nfactors, (ncells, ngenes) = self.nfactors, X.shape
         a, ap, c, cp = self.a, self.ap, self.c, self.cp
 
@@ -315,8 +317,18 @@ class scHPF(BaseEstimator):
             import os
             device = int(os.environ.get("SCHPF_DEVICE", "0"))
         model_dtype = np.dtype(self.dtype)
-        with DeviceCAVI(ncells, ngenes, nfactors, dtype=model_dtype, device=device) as eng:
-            eng.upload(X)
+        if batched:
+            return self._fit_minibatch(X, bp, dp, xi, eta, theta, beta, monitor, freeze_genes, reinit,
+                                       loss_function, max_iter, check_freq, checkstep_function, verbose,
+                                       batchsize, beta_theta_simultaneous, device)
+        own_engine = engine is None
+        eng = DeviceCAVI(ncells, ngenes, nfactors, dtype=model_dtype, device=device) if own_engine else engine
+        if not own_engine and ((eng.ncells, eng.ngenes, eng.nfactors) != (ncells, ngenes, nfactors)
+                               or eng.dtype != model_dtype or eng.nnz != X.data.shape[0]):
+            raise ValueError("engine was built for a different matrix, nfactors or dtype")
+        try:
+            if own_engine:
+                eng.upload(X)
             eng.set_hypers(a, c, bp, dp)
             for name, g in (("xi", xi), ("theta", theta), ("eta", eta), ("beta", beta)):
                 eng.set_gamma(name, g.vi_shape, g.vi_rate)
@@ -360,9 +372,63 @@ class scHPF(BaseEstimator):
                     break
 
             xi_new, eta_new, theta_new, beta_new = download()
+        finally:
+            if own_engine:
+                eng.close()
         if freeze_genes:    # the reference hands back the very objects it was given
             eta_new, beta_new = eta, beta
         return (bp, dp, xi_new, eta_new, theta_new, beta_new, monitor.loss)
+
+    def _fit_minibatch(self, X, bp, dp, xi, eta, theta, beta, monitor, freeze_genes, reinit, loss_function,
+                       max_iter, check_freq, checkstep_function, verbose, batchsize,
+                       beta_theta_simultaneous, device):
+        """Minibatch CAVI (scHPF_.py:643-650, 688-704): each iteration updates a batch of cells
+        first (theta.rate from the current beta), then the genes from that batch alone."""
+        from .util import minibatch_ix_generator
+        nfactors = self.nfactors
+        a, ap, c, cp = self.a, self.ap, self.c, self.cp
+        Xcsr = X.tocsr()
+        batches = minibatch_ix_generator(X.shape[0], batchsize)
+        if loss_function is None:
+            loss_function = ls.loss_function_for_data(ls.mean_negative_pois_llh, X)
+        dtype = np.dtype(self.dtype)
+        for t in range(max_iter):
+            batch_ix = next(batches)
+            X_batch = Xcsr[batch_ix, :].tocoo()
+            with DeviceCAVI(len(batch_ix), X.shape[1], nfactors, dtype=dtype, device=device) as eng:
+                eng.upload(X_batch)
+                eng.set_hypers(a, c, bp, dp)
+                eng.set_gamma("xi", xi.vi_shape[batch_ix], xi.vi_rate[batch_ix])
+                eng.set_gamma("theta", theta.vi_shape[batch_ix], theta.vi_rate[batch_ix])
+                eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
+                eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
+                if t == 0 and reinit:
+                    random_phi = np.random.dirichlet(np.ones(nfactors), X_batch.data.shape[0])
+                    eng.init_phi_host(X_batch.data[:, None] * random_phi)
+                eng.step(freeze_genes=freeze_genes, simultaneous=beta_theta_simultaneous,
+                         cells_first=not beta_theta_simultaneous)
+                ths, thr = eng.get_gamma("theta")
+                theta.vi_shape[batch_ix], theta.vi_rate[batch_ix] = ths, thr
+                xi.vi_rate[batch_ix] = eng.get_gamma("xi")[1]
+                if not freeze_genes:
+                    beta = HPF_Gamma(*eng.get_gamma("beta"))
+                    eta = HPF_Gamma(eta.vi_shape, eng.get_gamma("eta")[1])
+            if t % check_freq == 0:
+                curr = loss_function(a=a, ap=ap, bp=bp, c=c, cp=cp, dp=dp, xi=xi, eta=eta, theta=theta,
+                                     beta=beta)
+                curr, pct = monitor.record(curr)
+                if verbose:
+                    print("[Iter. {0: >4}]  loss:{1:.6f}  pct:{2:.9f}".format(t, curr, pct))
+                if checkstep_function is not None:
+                    checkstep_function(bp=bp, dp=dp, xi=xi, eta=eta, theta=theta, beta=beta, t=t)
+                outcome = monitor.verdict(t)
+                if outcome is not None:
+                    if verbose:
+                        print(outcome)
+                    break
+            if t >= self.max_iter:
+                break
+        return (bp, dp, xi, eta, theta, beta, monitor.loss)
 
     def _setup(self, X, freeze_genes=False, reinit=True, clip=True):
         """Empirical bp/dp and (re)initialised Gammas, draw order xi, theta, eta, beta

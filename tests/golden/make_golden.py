@@ -23,6 +23,7 @@ What each file pins (reference file:line):
                        reference's conftest recipe (tests/conftest.py:10-38)
   fit_*.npz            whole scHPF.fit()/project() traces (scHPF_.py:425-503,
                        526-780): bp, dp, per-check loss, final xi/theta/eta/beta
+  trials_data_k5_f64.npz  run_trials / run_trials_pool (scHPF_.py:968-1332): winner and losses
   pbmc_like_data.npz   the COO the reference's loader makes of its own test data
                        file tests/_data/PJ030merge...matrix.txt (data only)
   ref_model_f64.joblib a model file written by the reference's save_model
@@ -149,7 +150,26 @@ def make_project(model, X, fname, seed=7):
     np.savez_compressed(os.path.join(HERE, fname), **d)
 
 
+def make_trials(X, fname):
+    """run_trials (scHPF_.py:968-1147): 3 restarts, best final loss wins; also the reprojected
+    variant.  Losses of every restart are kept so the selection can be checked."""
+    import schpf as ref
+    np.random.seed(11)
+    best, rest = ref.run_trials(X, 5, ntrials=3, max_iter=30, verbose=False, return_all=True)
+    d = trace(best, X, best.loss, dict(seed=11, rejected_final=np.array([m.loss[-1] for m in rest])))
+    np.random.seed(12)
+    bests = ref.run_trials_pool(X, [4, 6], ntrials=2, njobs=1, max_iter=20, verbose=False)
+    d["pool_nfactors"] = np.array([m.nfactors for m in bests])
+    d["pool_checks"] = np.array([len(m.loss) for m in bests])
+    np.savez_compressed(os.path.join(HERE, fname), **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "trials":
+        txt = "/root/reference/tests/_data/PJ030merge.c300t400_g0t500.matrix.txt"
+        Xd, _genes = prep.load_txt(txt, verbose=False)
+        make_trials(Xd, "trials_data_k5_f64.npz")
+        return
     make_psi_gammaln()
     make_ops(np.float64, "f64")
     make_ops(np.float32, "f32")
@@ -172,6 +192,7 @@ def main():
     make_fit(Xd, 5, 3, np.float64, "fit_data_k5_s3_f64_batch.npz", max_iter=30,
              batchsize=32)
     make_project(m64, Xd, "project_data_k5_f64.npz")
+    make_trials(Xd, "trials_data_k5_f64.npz")
     schpf.save_model(m64, os.path.join(HERE, "ref_model_f64.joblib"))
     print("golden vectors written to", HERE)
 

@@ -334,3 +334,47 @@ def test_sharded_protocol_two_engines_on_one_gpu(amd, oracle, flags):
     assert_allclose(loss, want, rtol=1e-11)
     for e in engines:
         e.close()
+
+
+def test_minibatch_fit_reproduces_reference_trace(amd):
+    """batchsize=32 (reference scHPF_.py:626-650, 688-704): cell block first, genes from the
+    batch; same shuffle, same Dirichlet draws, same losses and parameters."""
+    from schpf import scHPF
+    g = load_golden("fit_data_k5_s3_f64_batch.npz")
+    X = golden_coo(g)
+    np.random.seed(int(g["seed"]))
+    model = scHPF(5, max_iter=int(g["max_iter"]), verbose=False)
+    model.fit(X, batchsize=32)
+    assert model.bp == float(g["bp"]) and model.dp == float(g["dp"])
+    assert len(model.loss) == len(g["loss"])
+    assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    for name in ("xi", "theta", "eta", "beta"):
+        assert_allclose(getattr(model, name).vi_shape, g[name + "_shape"], rtol=1e-7, err_msg=name)
+        assert_allclose(getattr(model, name).vi_rate, g[name + "_rate"], rtol=1e-7, err_msg=name)
+
+
+def test_run_trials_reproduces_reference_selection(amd, capsys):
+    """run_trials / run_trials_pool (reference scHPF_.py:968-1332): same seeds -> same winner,
+    same losses for the winner and the rejected restarts."""
+    from schpf import run_trials, run_trials_pool
+    g = load_golden("trials_data_k5_f64.npz")
+    X = golden_coo(g)
+    np.random.seed(int(g["seed"]))
+    best, rest = run_trials(X, 5, ntrials=3, max_iter=30, verbose=False, return_all=True)
+    assert_allclose(best.loss, g["loss"], rtol=1e-9)
+    assert_allclose([m.loss[-1] for m in rest], g["rejected_final"], rtol=1e-9)
+    assert_allclose(best.theta.vi_shape, g["theta_shape"], rtol=1e-6)
+    assert_allclose(best.beta.vi_rate, g["beta_rate"], rtol=1e-6)
+    assert best.loss[-1] <= min(m.loss[-1] for m in rest)
+    np.random.seed(12)
+    bests = run_trials_pool(X, [4, 6], ntrials=2, njobs=1, max_iter=20, verbose=False)
+    assert [m.nfactors for m in bests] == list(g["pool_nfactors"])
+    assert [len(m.loss) for m in bests] == list(g["pool_checks"])
+    # reproject=True appends the projection's loss list and selects on its last value
+    np.random.seed(1)
+    m = run_trials(X, 4, ntrials=2, max_iter=12, verbose=False, reproject=True)
+    assert isinstance(m.loss[-1], list) and m.theta.dims == (100, 4)
+    # validation cells through projection_loss_function
+    np.random.seed(2)
+    m = run_trials(X, 4, ntrials=1, max_iter=12, verbose=False, vcells=X.tocsr()[:30].tocoo())
+    assert len(m.loss) == 2 and np.isfinite(m.loss[-1])

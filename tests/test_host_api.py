@@ -171,6 +171,28 @@ def test_project_argument_check(model, data):
         model.project(data, recalc_bp=True, replace=True)
 
 
-def test_minibatch_not_silently_ignored(model, data):
-    with pytest.raises(NotImplementedError):
-        model._fit(data, batchsize=32)
+def test_minibatch_generator_cycles_and_wraps():
+    from schpf.util import minibatch_ix_generator
+    np.random.seed(5)
+    gen = minibatch_ix_generator(10, 4)
+    got = [next(gen) for _ in range(5)]
+    np.random.seed(5)
+    order = np.arange(10); np.random.shuffle(order)
+    assert_array_equal(got[0], order[:4]); assert_array_equal(got[1], order[4:8])
+    assert_array_equal(got[2], np.hstack([order[8:], order[:2]]))      # wraps around
+    assert_array_equal(got[3], order[2:6])
+    assert sorted(np.concatenate(got[:5])[:10]) == sorted(order)
+    gen = minibatch_ix_generator(8, 8)
+    assert len(next(gen)) == 8 and len(next(gen)) == 8
+
+
+def test_trial_drivers_exported():
+    from schpf import run_trials, run_trials_pool
+    import inspect
+    sig = inspect.signature(run_trials)
+    for name in ("X", "nfactors", "ntrials", "min_iter", "max_iter", "check_freq", "epsilon",
+                 "better_than_n_ago", "dtype", "verbose", "vcells", "vX", "loss_function", "model_kwargs",
+                 "return_all", "reproject", "reproject_kwargs", "batchsize", "beta_theta_simultaneous",
+                 "loss_smoothing"):
+        assert name in sig.parameters
+    assert "njobs" in inspect.signature(run_trials_pool).parameters
