@@ -361,19 +361,20 @@ template <typename T> struct Engine final : schpf_ctx {
         tile_shape(N, G, wpb_c, wr_c, tk_c);
         tile_shape(G, N, wpb_g, wr_g, tk_g);
         const bool allow_pack = env_int("SCHPF_PACK", 1) != 0;
+        const int row_slots = env_int("SCHPF_BANK_ORDER", 1) ? (int)((size_t)KP * sizeof(T) / 16) : 0;
         std::exception_ptr err;
         double secs_gene = 0.0;
         std::thread side([&] {
             try {
                 const double t0 = now_s();
-                schpf::build_tile_plan(nnz, col, row, val, G, N, LPC, wpb_g, wr_g, tk_g, true, allow_pack, tgene.host);
+                schpf::build_tile_plan(nnz, col, row, val, G, N, LPC, wpb_g, wr_g, tk_g, true, allow_pack, row_slots, tgene.host);
                 secs_gene = now_s() - t0;
             } catch (...) { err = std::current_exception(); }
         });
         double secs_cell = 0.0;
         try {
             const double t0 = now_s();
-            schpf::build_tile_plan(nnz, row, col, val, N, G, LPC, wpb_c, wr_c, tk_c, true, allow_pack, tcell.host);
+            schpf::build_tile_plan(nnz, row, col, val, N, G, LPC, wpb_c, wr_c, tk_c, true, allow_pack, row_slots, tcell.host);
             secs_cell = now_s() - t0;
         } catch (...) { side.join(); throw; }
         side.join();
@@ -1128,7 +1129,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
     return guarded([&] {
         schpf::TilePlanHost P;
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, lpc, waves_per_block, win_rows,
-                               target_tasks, false, getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true, P);
+                               target_tasks, false, getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true, 10, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
         int64_t n = 0;
         for (int64_t t = 0; t < P.n_tasks; ++t) {

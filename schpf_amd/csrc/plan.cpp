@@ -250,9 +250,42 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 }
 
 
+// LDS-bank-aware order of one row segment (tile plan).  A lane group reads the gathered row with
+// ds_read_b128; the LDS serves 16 lanes (= 16/lpc lane groups, one "pass") per cycle and those
+// reads are conflict-free iff their 16-byte slots differ modulo 16.  A table row occupies
+// `row_slots` slots, so the slot base of local row r is (r * row_slots) mod 16 and its class is
+// base / lpc.  The group with rank j inside its pass wants class (j + t) mod n_classes at position
+// t: if every group of a pass gets its wish, the pass touches each slot once.  Greedy: take the
+// wished class if the segment still has such a nonzero, else from the fullest class.
+// seq[t] = index (within the segment) of the nonzero placed at position t.
+static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_slots, int lpc, int rank,
+                       std::vector<int32_t> &seq, std::vector<std::vector<int32_t>> &buckets)
+{
+    const int n_classes = std::max(1, 16 / std::max(1, lpc));
+    if (n_classes == 1 || n <= 2) {
+        for (int t = 0; t < n; ++t) seq[(size_t)t] = t;
+        return;
+    }
+    for (int c = 0; c < n_classes; ++c) buckets[(size_t)c].clear();
+    for (int i = n - 1; i >= 0; --i) {   // reversed so that pop_back() hands them out in minor order
+        const int cls = (int)(((int64_t)(seg_minor[i] - base) * row_slots) % 16) / lpc;
+        buckets[(size_t)(cls % n_classes)].push_back(i);
+    }
+    for (int t = 0; t < n; ++t) {
+        int c = (rank + t) % n_classes;
+        if (buckets[(size_t)c].empty()) {
+            size_t best = 0;
+            for (int k = 0; k < n_classes; ++k)
+                if (buckets[(size_t)k].size() > best) { best = buckets[(size_t)k].size(); c = k; }
+        }
+        seq[(size_t)t] = buckets[(size_t)c].back();
+        buckets[(size_t)c].pop_back();
+    }
+}
+
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                      int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, bool allow_packed, TilePlanHost &P)
+                     int target_tasks, bool keep_order, bool allow_packed, int row_slots, TilePlanHost &P)
 {
     if (lpc < 1 || lpc > 64 || (64 % lpc) != 0) throw std::invalid_argument("lpc must divide 64");
     if (waves_per_block < 1 || waves_per_block > 16) throw std::invalid_argument("waves_per_block in [1,16]");
@@ -374,15 +407,32 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     }
     P.packed = packed;
     const int epw = packed ? 2 : 4;      // 32-bit words per step slot
-    P.entries.resize((size_t)total * epw);
-    parallel_for(total * epw, nth, [&](int64_t b, int64_t e, int) {
+    // + zero slots: the kernel's ring prefetch (depth 4, advanced in batches of 4) reads up to
+    // 2 * 4 - 1 steps past a wave's last entry; 12 steps of padding keep that inside the buffer
+    const int64_t total_padded = total + (int64_t)12 * gpw;
+    P.entries.resize((size_t)total_padded * epw);
+    parallel_for(total_padded * epw, nth, [&](int64_t b, int64_t e, int) {
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
     P.task_wave_off.resize((size_t)P.n_tasks * wpb);
     P.task_wave_end.resize((size_t)P.n_tasks * wpb);
     // fill: walk each row's nonzeros in minor order; position inside its window segment = t
+    // rank of every group of a wave inside its ds_read_b128 pass (16 lanes served per LDS cycle)
+    std::vector<int> pass_rank((size_t)gpw, 0);
+    {
+        static const int pass_of_quad[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};  // lanes 4q..4q+3
+        int seen[4] = {0, 0, 0, 0};
+        for (int g2 = 0; g2 < gpw; ++g2) {
+            const int lane0 = g2 * lpc;
+            if (lpc > 16) { pass_rank[(size_t)g2] = 0; continue; }
+            const int ps = pass_of_quad[lane0 / 4];
+            pass_rank[(size_t)g2] = seen[ps]++;
+        }
+    }
     parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
         std::vector<int64_t> win_off((size_t)W);
+        std::vector<int32_t> seq;
+        std::vector<std::vector<int32_t>> buckets(16);
         for (int64_t b = b0; b < b1; ++b) {
             for (int v = 0; v < wpb; ++v) {
                 const size_t bw = (size_t)b * wpb + v;
@@ -401,23 +451,32 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                 int64_t off = wave_off[bw];
                 for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += (int64_t)P.steps[bw * W + w] * gpw; }
                 const int slot = g % gpw;
-                int32_t cur_w = -1, t = 0;
-                for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) {
-                    const int32_t mn = s_minor[(size_t)j];
-                    const int32_t w = mn / win_rows;
-                    if (w != cur_w) { cur_w = w; t = 0; }
-                    const size_t step_slot = (size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot;
-                    if (packed) {
-                        uint32_t *e = P.entries.data() + step_slot * 2;
-                        const int sh = (t & 1) * 16;
-                        e[0] |= (uint32_t)(mn - w * win_rows) << sh;
-                        e[1] |= (uint32_t)s_val[(size_t)j] << sh;
-                    } else {
-                        uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
-                        e[0] = (uint32_t)(mn - w * win_rows);
-                        e[1] = f2u(s_val[(size_t)j]);
+                // one window segment at a time; inside it the nonzeros may be taken in any order,
+                // so they are dealt to the steps in an LDS-bank-aware order (see bank_order)
+                int64_t j = mptr[row];
+                const int64_t end = mptr[(size_t)row + 1];
+                while (j < end) {
+                    const int32_t w = s_minor[(size_t)j] / win_rows;
+                    int64_t s = j;
+                    while (j < end && s_minor[(size_t)j] / win_rows == w) ++j;
+                    const int n = (int)(j - s);
+                    seq.resize((size_t)n);
+                    bank_order(s_minor.data() + s, n, w * win_rows, row_slots, lpc, pass_rank[(size_t)slot], seq, buckets);
+                    for (int t = 0; t < n; ++t) {
+                        const int64_t src = s + seq[(size_t)t];
+                        const int32_t mn = s_minor[(size_t)src];
+                        const size_t step_slot = (size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot;
+                        if (packed) {
+                            uint32_t *e = P.entries.data() + step_slot * 2;
+                            const int sh = (t & 1) * 16;
+                            e[0] |= (uint32_t)(mn - w * win_rows) << sh;
+                            e[1] |= (uint32_t)s_val[(size_t)src] << sh;
+                        } else {
+                            uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
+                            e[0] = (uint32_t)(mn - w * win_rows);
+                            e[1] = f2u(s_val[(size_t)src]);
+                        }
                     }
-                    ++t;
                 }
             }
         }

@@ -93,9 +93,11 @@ struct TilePlanHost {
     std::vector<int64_t> mptr;            // [n_major + 1]
 };
 
+// row_slots: 16-byte slots per table row (KP * sizeof(T) / 16), for the LDS-bank-aware ordering of
+// the nonzeros inside a row segment (0 = keep minor order).
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                      int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, bool allow_packed, TilePlanHost &out);
+                     int target_tasks, bool keep_order, bool allow_packed, int row_slots, TilePlanHost &out);
 
 // positions sorted by (major, minor) and the per-major run pointers
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
