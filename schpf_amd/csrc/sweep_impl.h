@@ -530,9 +530,15 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
                                 any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
 #pragma unroll
                                 for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, b1[k], fma_t(q0, b0[k], acc[k]));
-                            } else {
+                            } else if (LPC == 1) {
                                 if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
                                 if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
+                            } else {
+                                // every lane of the group knows s0 and s1: lane 0 takes the log of the
+                                // first nonzero, lane 1 of the second (the f64 log is the costly part)
+                                const T sm = (sub & 1) ? s1 : s0;
+                                const T xm = (sub & 1) ? x1 : x0;
+                                if (sub < 2 && xm > T(0)) llh += (double)xm * log((double)sm) - (double)sm;
                             }
                         } else {
 #pragma unroll 1
@@ -569,7 +575,9 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
     }
 
     if (MODE == MODE_LLH) {
-        if (sub != 0) llh = 0.0;
+        // which lanes hold a share: all (LPC 1), lanes 0-1 of a group (paired steps), lane 0 (else)
+        constexpr bool PAIRED = KL * (int)sizeof(T) <= 96;
+        if (LPC > 1 && !(PAIRED ? sub < 2 : sub == 0)) llh = 0.0;
         llh = wave_sum(llh);
         if (lane == 0) a.wave_out[(size_t)task * a.wpb + wv] = llh;
         return;
