@@ -49,6 +49,10 @@ extern "C" {
 #define SCHPF_SIMULTANEOUS 2u   /* beta_theta_simultaneous=True (scHPF_.py:666-685)      */
 #define SCHPF_CELLS_FIRST 8u    /* minibatch order (scHPF_.py:688-704): xi/theta block first (theta.rate
                                    from the current beta), then the gene block from the NEW theta    */
+#define SCHPF_LOCAL_GENE 16u    /* schpf_step_local: only the gene-side sweep (+ packing)           */
+#define SCHPF_LOCAL_CELL 32u    /* schpf_step_local: only the cell-side sweep; neither bit = both.
+                                   Lets the host start the all-reduce of the gene-side sums and
+                                   overlap it with the cell-side sweep.                             */
 #define SCHPF_SHARDED 4u        /* cells are sharded over several GPUs: gene-side sums go
                                    through the exchange buffer (all-reduced by the host) */
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libschpf_hip.so")
 F32, F64 = 0, 1
 XI, THETA, ETA, BETA = 0, 1, 2, 3
 VAL_I32, VAL_I64, VAL_F32, VAL_F64 = 0, 1, 2, 3
-FREEZE_GENES, SIMULTANEOUS, SHARDED, CELLS_FIRST = 1, 2, 4, 8
+FREEZE_GENES, SIMULTANEOUS, SHARDED, CELLS_FIRST, LOCAL_GENE, LOCAL_CELL = 1, 2, 4, 8, 16, 32
 
 _vp = ctypes.c_void_p
 _i32p = ctypes.POINTER(ctypes.c_int32)

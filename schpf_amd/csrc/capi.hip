@@ -672,19 +672,21 @@ template <typename T> struct Engine final : schpf_ctx {
         refresh_tables();
         const bool freeze = flags_ & SCHPF_FREEZE_GENES;
         const bool sharded = flags_ & SCHPF_SHARDED;
+        const bool only_gene = flags_ & SCHPF_LOCAL_GENE, only_cell = flags_ & SCHPF_LOCAL_CELL;
+        const bool do_cell = !only_gene || only_cell, do_gene = !only_cell || only_gene;
         if (pending_init == 0) {
-            {
-                ScopedTimer tm(prof, stream, 0);
-                run_sweep(0, schpf::MODE_PHI);
-                tm.stop();
-            }
-            if (!freeze) {
+            if (do_gene && !freeze) {
                 ScopedTimer tm(prof, stream, 1);
                 run_sweep(1, schpf::MODE_PHI);
                 tm.stop();
             }
+            if (do_cell) {
+                ScopedTimer tm(prof, stream, 0);
+                run_sweep(0, schpf::MODE_PHI);
+                tm.stop();
+            }
         }
-        if (sharded && !freeze && pending_init != 1) {
+        if (sharded && !freeze && pending_init != 1 && do_gene) {
             // fixed-order reduction of this rank's gene-side partials into the exchange buffer
             if (use_tile)
                 HIPCHK(schpf::launch_combine_strided<T>(tgene.partials.as<T>(), tgene.pfirst.as<int>(),

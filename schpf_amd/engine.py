@@ -132,8 +132,12 @@ class DeviceCAVI(object):
         _lib.check(self._lib.schpf_step(self._h, self._flags(freeze_genes, simultaneous,
                                                              cells_first=cells_first)))
 
-    def step_local(self, freeze_genes=False, simultaneous=False):
-        _lib.check(self._lib.schpf_step_local(self._h, self._flags(freeze_genes, simultaneous, True)))
+    def step_local(self, freeze_genes=False, simultaneous=False, side=None):
+        """Sweeps of the sharded iteration.  side=None: both; 'gene': the gene-side sweep and the
+        packing of its sums into the exchange buffer; 'cell': the cell-side sweep (so that the
+        caller can overlap it with the all-reduce of the gene-side sums)."""
+        extra = {None: 0, "gene": _lib.LOCAL_GENE, "cell": _lib.LOCAL_CELL}[side]
+        _lib.check(self._lib.schpf_step_local(self._h, self._flags(freeze_genes, simultaneous, True) | extra))
 
     def step_finish(self, freeze_genes=False, simultaneous=False):
         _lib.check(self._lib.schpf_step_finish(self._h, self._flags(freeze_genes, simultaneous, True)))

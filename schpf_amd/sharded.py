@@ -5,10 +5,11 @@ the model itself: given beta/eta, cells are independent (schpf/scHPF_.py:706-714
 and genes only need sums over cells (:699-703).  So rank p keeps a contiguous block
 of rows of X with its xi/theta slices and a replica of eta/beta, and one iteration is
 
-    step_local   both sweeps on the local rows; gene-side sums (G*K) and the local
+    step_local   gene-side sweep on the local rows; its sums (G*K) and the local
                  sum_i E[theta_ik] (K) are packed into one device buffer
     all_reduce   ONE sum all-reduce of that buffer (torch.distributed; backend "nccl"
-                 is RCCL on ROCm)
+                 is RCCL on ROCm), started asynchronously ...
+    step_local   ... so that the cell-side sweep runs underneath it
     step_finish  every rank applies the identical beta/eta update to its replica,
                  then its own theta/xi update
 
@@ -68,10 +69,16 @@ class ShardedCAVI(object):
         self.group = group
 
     def step(self, freeze_genes=False, simultaneous=False):
-        self.engine.step_local(freeze_genes=freeze_genes, simultaneous=simultaneous)
-        if not freeze_genes:
-            self.dist.all_reduce(self.exchange, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.engine.step_finish(freeze_genes=freeze_genes, simultaneous=simultaneous)
+        if freeze_genes:                       # nothing to exchange
+            self.engine.step_local(freeze_genes=True, simultaneous=simultaneous)
+            self.engine.step_finish(freeze_genes=True, simultaneous=simultaneous)
+            return
+        # gene-side sweep -> start the all-reduce of its sums -> cell-side sweep runs under it
+        self.engine.step_local(simultaneous=simultaneous, side="gene")
+        work = self.dist.all_reduce(self.exchange, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.engine.step_local(simultaneous=simultaneous, side="cell")
+        work.wait()
+        self.engine.step_finish(simultaneous=simultaneous)
 
     def mean_negative_pois_llh(self):
         import torch

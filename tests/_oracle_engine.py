@@ -39,7 +39,9 @@ class OracleEngine(object):
     def init_phi_host(self, xphi):
         self.pending_xphi = np.asarray(xphi, dtype=np.float64)
 
-    def step_local(self, freeze_genes=False, simultaneous=False):
+    def step_local(self, freeze_genes=False, simultaneous=False, side=None):
+        if side == "cell":
+            return                         # this stand-in does both sides in the 'gene' (or only) call
         X, K = self.X, self.K
         ths, thr = self.g["theta"]
         bes, ber = self.g["beta"]

@@ -378,3 +378,40 @@ def test_run_trials_reproduces_reference_selection(amd, capsys):
     np.random.seed(2)
     m = run_trials(X, 4, ntrials=1, max_iter=12, verbose=False, vcells=X.tocsr()[:30].tocoo())
     assert len(m.loss) == 2 and np.isfinite(m.loss[-1])
+
+
+def test_rccl_all_reduce_accepts_the_exchange_buffer(amd, oracle):
+    """One-rank NCCL(=RCCL) process group on the GPU box: the sharded driver's all_reduce runs
+    on a torch view of library-owned HBM (same HIP runtime, see schpf_amd/_lib.py) and the
+    sharded step equals the plain step."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from schpf_amd.sharded import ShardedCAVI, exchange_tensor_of
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        X = synthetic_counts(700, 500, 0.06, seed=17)
+        K, a, c = 20, 0.3, 0.3
+        bp, dp, st = random_state(oracle, X, K, np.float64, seed=6)
+        stream = torch.cuda.current_stream().cuda_stream
+        eng = amd.DeviceCAVI(700, 500, K, dtype=np.float64, device=0, stream=stream)
+        eng.upload(X)
+        eng.set_hypers(a, c, bp, dp)
+        for name in ("xi", "theta", "eta", "beta"):
+            eng.set_gamma(name, getattr(st, name + "_shape"), getattr(st, name + "_rate"))
+        drv = ShardedCAVI(eng, exchange_tensor_of(eng, 0))
+        for _ in range(3):
+            drv.step()
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+        compare_state(eng, st, rtol=1e-11)
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                             st.beta_shape, st.beta_rate)
+        assert_allclose(drv.mean_negative_pois_llh(), want, rtol=1e-11)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
