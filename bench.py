@@ -243,6 +243,17 @@ def main():
     sweep_ms = (prof["cell_sweep"]["ms"] + prof["gene_sweep"]["ms"]) / max(sweeps, 1)
     achieved = (b_iter / 2.0) / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     info = eng.plan_info()
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (collected separately, as PMC
+    # must be; profiles/r01/pmc_traffic.json), only for the configuration they were taken on
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+            rec = json.load(fh).get("%s/%s" % (args.config, args.dtype))
+        if rec and world == 1:
+            traffic = rec["bytes_per_launch"] / 1e9
+            traffic_src = "profiles/r01/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) per launch, GB"
+    except (OSError, ValueError, KeyError):
+        pass
 
     out = {
         "metric": "CAVI iterations/sec, 100kx20k K=20" if args.config == "c3"
@@ -263,7 +274,8 @@ def main():
             "bound": "hbm", "kernel": "sweep_kernel (cell + gene launches; algorithmic bytes per "
                                       "launch = B_iter/2, B_iter = 12*nnz + 4*K*s*(N+G) + 2*s*(N+G))",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_gb_per_launch": b_iter / 2.0 / 1e9,
             "avg_launch_ms": sweep_ms, "launches": sweeps,
             "cell_sweep_ms": prof["cell_sweep"]["ms"] / max(prof["cell_sweep"]["launches"], 1),
             "gene_sweep_ms": prof["gene_sweep"]["ms"] / max(prof["gene_sweep"]["launches"], 1),
