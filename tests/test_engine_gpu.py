@@ -415,3 +415,38 @@ def test_rccl_all_reduce_accepts_the_exchange_buffer(amd, oracle):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_skewed_expression_matrix_matches_oracle(amd, oracle):
+    """Real count matrices are heavy-tailed: a few genes are seen in almost every cell, most in
+    a handful, and cell depths vary several-fold.  Zipf-distributed gene popularity, log-normal
+    depths, a few all-zero cells and genes, counts up to the thousands (and one above 65535, which
+    forces the unpacked entry format)."""
+    rng = np.random.RandomState(23)
+    N, G, K = 900, 1300, 10
+    pop = 1.0 / np.arange(1, G + 1) ** 1.1
+    pop[rng.permutation(G)[:40]] = 0.0                       # never-seen genes
+    depth = np.exp(rng.normal(5.0, 0.7, N)).astype(int)
+    depth[rng.permutation(N)[:15]] = 0                       # empty cells
+    rows, cols = [], []
+    cdf = np.cumsum(pop) / pop.sum()
+    for i in range(N):
+        g = np.searchsorted(cdf, rng.random_sample(depth[i]))
+        rows.append(np.full(g.shape, i, np.int32)); cols.append(g.astype(np.int32))
+    row, col = np.concatenate(rows), np.minimum(np.concatenate(cols), G - 1)
+    from scipy.sparse import coo_matrix
+    X = coo_matrix((np.ones(row.shape[0], np.int64), (row, col)), shape=(N, G))
+    X.sum_duplicates()
+    for big in (False, True):
+        if big:
+            X.data[np.argmax(X.data)] = 70000                # > 16 bits: unpacked entries
+        a, c = 0.3, 0.3
+        bp, dp, st = random_state(oracle, X, K, np.float64, seed=8)
+        with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+            for _ in range(3):
+                eng.step()
+                oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+            compare_state(eng, st, rtol=1e-10)
+            want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                                 st.beta_shape, st.beta_rate)
+            assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-10)
