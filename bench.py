@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the sharded driver (process group, exchange all-reduce) even with one rank")
     ap.add_argument("--converge", action="store_true",
                     help="also time a whole fit() to convergence on planted data (N=1 only, adds minutes)")
     args = ap.parse_args()
@@ -173,8 +175,10 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
                              "--gpus %d ..." % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -193,7 +197,7 @@ def main():
     init_engine(eng, X, K, dtype)
     upload_s = time.perf_counter() - t_up
     nnz_local = X.nnz
-    if world > 1:
+    if sharded:
         drv = ShardedCAVI(eng, exchange_tensor_of(eng, local_rank))
         step = drv.step
         nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
@@ -206,7 +210,7 @@ def main():
         loss_fn = eng.mean_negative_pois_llh
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -224,7 +228,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile(False)
-    if world > 1:
+    if sharded:
         el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -296,7 +300,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

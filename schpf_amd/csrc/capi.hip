@@ -591,7 +591,6 @@ template <typename T> struct Engine final : schpf_ctx {
         a.wave_out = wave_out.as<double>();
         a.K = K; a.n_minor = n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
         a.wpb = td.host.wpb;
-        a.debug = env_int("SCHPF_DEBUG_TILE", 0);
         return a;
     }
 

@@ -41,7 +41,6 @@ template <typename T> struct TileArgs {
     int K, n_minor, n_windows, win_rows, wpb;
     uint64_t seed;                 // MODE_RANDOM
     int major_is_cell;
-    int debug;                     // timing experiments only (SCHPF_DEBUG_TILE): 1 = skip staging copy, 2 = skip barriers
 };
 
 template <typename T> struct UpdateArgs {

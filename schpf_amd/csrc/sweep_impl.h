@@ -477,14 +477,14 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 
     for (int w = w0; w < w1; ++w) {
         if (MODE != MODE_RANDOM) {
-            if (!(a.debug & 2) || w == w0) __syncthreads();   // previous window fully consumed
+            __syncthreads();                       // previous window fully consumed
             const int r0 = w * a.win_rows;
             const int nr = min(a.win_rows, a.n_minor - r0);
             const V *__restrict__ src = reinterpret_cast<const V *>(a.tab_minor + (size_t)r0 * KP);
             V *dst = reinterpret_cast<V *>(win);
-            const int nvec = ((a.debug & 1) && w != w0) ? 0 : nr * (KP / VEC);   // debug: stage the first window only
+            const int nvec = nr * (KP / VEC);
             for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
-            if (!(a.debug & 2) || w == w0) __syncthreads();
+            __syncthreads();
         }
         for (int p = 0; p < steps; p += RING) {
 #pragma unroll
