@@ -147,10 +147,16 @@ template <typename T> __device__ __forceinline__ T safe_weight(T x, T s, bool ok
 template <typename T, int KL, int LPC>
 __device__ __forceinline__ T group_dot(const T (&x)[KL], const T (&y)[KL])
 {
-    T s = T(0);
+    // two independent partial sums: a single chain of KL dependent FMAs leaves the SIMD idle
+    // whenever fewer than ~4 waves have VALU work ready (f64 FMA result latency > issue time)
+    T s0 = T(0), s1 = T(0);
 #pragma unroll
-    for (int k = 0; k < KL; ++k) s += x[k] * y[k];
-    return group_sum<T, LPC>(s);
+    for (int k = 0; k + 1 < KL; k += 2) {
+        s0 = fma_t(x[k], y[k], s0);
+        s1 = fma_t(x[k + 1], y[k + 1], s1);
+    }
+    if (KL & 1) s0 = fma_t(x[KL - 1], y[KL - 1], s0);
+    return group_sum<T, LPC>(s0 + s1);
 }
 
 
