@@ -76,10 +76,12 @@ template <typename T, int LPC> __device__ __forceinline__ int factor_of(int r, i
 // row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) complete an all-reduce over 16 lanes.
 template <int STEP> __device__ __forceinline__ int dpp_partner(int v)
 {
-    if (STEP == 0) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    if (STEP == 1) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    if (STEP == 2) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);                 // row_mirror
+    // every lane has a valid source under these patterns, so the `old` operand is never used;
+    // passing v itself spares the v_mov that would zero-initialise the destination
+    if (STEP == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);                 // row_mirror
 }
 template <int STEP> __device__ __forceinline__ float partner(float v)
 {
@@ -109,11 +111,12 @@ template <typename T, int LPC> __device__ __forceinline__ T group_max(T v)
 }
 
 // x / s for s known to be a normal positive number: hardware reciprocal + Newton steps instead
-// of the IEEE division sequence (no scaling / fix-up needed here).  <= 2 ulp.
+// of the IEEE division sequence (no scaling / fix-up needed here).  <= 2 ulp: v_rcp_f64 is good
+// to ~2^-24, one Newton step squares that (2^-48), and the residual correction of the quotient
+// multiplies the two errors (rounding level).
 __device__ __forceinline__ double fast_div(double x, double s)
 {
     double r = __builtin_amdgcn_rcp(s);
-    r = fma(fma(-s, r, 1.0), r, r);
     r = fma(fma(-s, r, 1.0), r, r);
     const double q = x * r;
     return fma(fma(-s, q, x), r, q);
@@ -135,11 +138,11 @@ __device__ __forceinline__ double wave_sum(double v)
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(a, b, c); }
 
-// x / s without a branch: padding entries carry x = 0 (weight 0); an underflowed normaliser
-// (ok == false) is divided as 1 and masked -- the cold path redoes that group afterwards.
+// x / s without a branch: padding entries carry x = 0 (weight 0); with an underflowed normaliser
+// (ok == false) the quotient is inf/NaN garbage and is masked -- the cold path redoes that group.
 template <typename T> __device__ __forceinline__ T safe_weight(T x, T s, bool ok)
 {
-    const T q = fast_div(x, ok ? s : T(1));
+    const T q = fast_div(x, s);
     return ok ? q : T(0);
 }
 
@@ -147,16 +150,32 @@ template <typename T> __device__ __forceinline__ T safe_weight(T x, T s, bool ok
 template <typename T, int KL, int LPC>
 __device__ __forceinline__ T group_dot(const T (&x)[KL], const T (&y)[KL])
 {
-    // two independent partial sums: a single chain of KL dependent FMAs leaves the SIMD idle
-    // whenever fewer than ~4 waves have VALU work ready (f64 FMA result latency > issue time)
-    T s0 = T(0), s1 = T(0);
+    // independent partial sums: a single chain of KL dependent FMAs leaves the SIMD idle whenever
+    // fewer than ~4 waves have VALU work ready.  f64: two chains.  f32: four, because the compiler
+    // packs pairs of chains into v_pk_fma_f32 and two chains would again be ONE dependent chain.
+    T t;
+    if constexpr (sizeof(T) == 4 && KL % 4 == 0) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k + 1 < KL; k += 2) {
-        s0 = fma_t(x[k], y[k], s0);
-        s1 = fma_t(x[k + 1], y[k + 1], s1);
+        for (int k = 0; k < KL; k += 4) {
+            const f32x2 x0 = {x[k], x[k + 1]}, y0 = {y[k], y[k + 1]};
+            const f32x2 x1 = {x[k + 2], x[k + 3]}, y1 = {y[k + 2], y[k + 3]};
+            a0 = __builtin_elementwise_fma(x0, y0, a0);
+            a1 = __builtin_elementwise_fma(x1, y1, a1);
+        }
+        t = (a0.x + a0.y) + (a1.x + a1.y);
+    } else {
+        T s0 = T(0), s1 = T(0);
+#pragma unroll
+        for (int k = 0; k + 1 < KL; k += 2) {
+            s0 = fma_t(x[k], y[k], s0);
+            s1 = fma_t(x[k + 1], y[k + 1], s1);
+        }
+        if (KL & 1) s0 = fma_t(x[KL - 1], y[KL - 1], s0);
+        t = s0 + s1;
     }
-    if (KL & 1) s0 = fma_t(x[KL - 1], y[KL - 1], s0);
-    return group_sum<T, LPC>(s0 + s1);
+    return group_sum<T, LPC>(t);
 }
 
 
@@ -477,33 +496,47 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 
     E ring[RING];
     int steps = __builtin_amdgcn_readfirstlane((int)st[w0]);
+    // every ring load is unconditional (the entry buffer is padded, plan.cpp), so the number of
+    // loads in flight is a compile-time fact and the waits can be s_waitcnt vmcnt(RING - 1)
 #pragma unroll
-    for (int i = 0; i < RING; ++i)
-        if (i < steps) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
+    for (int i = 0; i < RING; ++i) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
 
     for (int w = w0; w < w1; ++w) {
         if (MODE != MODE_RANDOM) {
             __syncthreads();                       // previous window fully consumed
             const int r0 = w * a.win_rows;
             const int nr = min(a.win_rows, a.n_minor - r0);
-            const V *__restrict__ src = reinterpret_cast<const V *>(a.tab_minor + (size_t)r0 * KP);
-            V *dst = reinterpret_cast<V *>(win);
-            const int nvec = nr * (KP / VEC);
-            for (int i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
+            // asynchronous global -> LDS copy (global_load_lds_dwordx4): a wave instruction moves
+            // 1 KiB (LDS address = wave-uniform base + 16 * lane), no staging registers and every
+            // piece of the window in flight at once; __syncthreads drains them (vmcnt(0)) first
+            const unsigned char *__restrict__ src = reinterpret_cast<const unsigned char *>(a.tab_minor + (size_t)r0 * KP);
+            const int nbytes = nr * KP * (int)sizeof(T);                  // a multiple of 16
+            for (int off = wv * 1024; off < nbytes; off += a.wpb * 1024) {   // scalar loop
+                const int o = off + lane * 16;
+                if (o < nbytes)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src + o),
+                        (__attribute__((address_space(3))) void *)(lds_raw + off), 16, 0, 0);
+            }
             __syncthreads();
         }
         for (int p = 0; p < steps; p += RING) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) {
+                const E c = ring[i];
+                unsigned i0 = EF::idx(c, 0), i1 = EF::idx(c, 1);
+                float xf0 = EF::val(c, 0), xf1 = EF::val(c, 1);
+                // decode before the refill so that the slot's registers are free for it (otherwise
+                // the refill lands in other registers and the loop needs copies behind a vmcnt(0))
+                asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xf0), "+v"(xf1));
+                ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);   // may run past: padded
                 if (p + i < steps) {                                   // scalar branch
-                    const E c = ring[i];
-                    if (p + i + RING < steps) ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
                     if (MODE == MODE_RANDOM) {
                         // t = 0 responsibilities (reference scHPF_.py:652-655), counter-based draws
 #pragma unroll 1
                         for (int u = 0; u < 2; ++u) {
-                            const unsigned minor = (unsigned)(w * a.win_rows) + EF::idx(c, u);
-                            const double x = (double)EF::val(c, u);
+                            const unsigned minor = (unsigned)(w * a.win_rows) + (u ? i1 : i0);
+                            const double x = (double)(u ? xf1 : xf0);
                             if (!(x > 0.0)) continue;
                             const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
                             const uint64_t gene = a.major_is_cell ? (uint64_t)minor : (uint64_t)major;
@@ -525,9 +558,9 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
                         constexpr bool PAIR = KL * (int)sizeof(T) <= 96;
                         if (PAIR) {
                             T b0[KL], b1[KL];
-                            load_lane<T, NV, LPC>(win + (size_t)EF::idx(c, 0) * KP, sub, b0);
-                            load_lane<T, NV, LPC>(win + (size_t)EF::idx(c, 1) * KP, sub, b1);
-                            const T x0 = (T)EF::val(c, 0), x1 = (T)EF::val(c, 1);
+                            load_lane<T, NV, LPC>(win + __umul24(i0, KP), sub, b0);
+                            load_lane<T, NV, LPC>(win + __umul24(i1, KP), sub, b1);
+                            const T x0 = (T)xf0, x1 = (T)xf1;
                             const T s0 = group_dot<T, KL, LPC>(tm, b0);
                             const T s1 = group_dot<T, KL, LPC>(tm, b1);
                             if (MODE == MODE_PHI) {
@@ -550,8 +583,8 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 #pragma unroll 1
                             for (int u = 0; u < 2; ++u) {
                                 T b[KL];
-                                load_lane<T, NV, LPC>(win + (size_t)EF::idx(c, u) * KP, sub, b);
-                                const T x = (T)EF::val(c, u);
+                                load_lane<T, NV, LPC>(win + __umul24(u ? i1 : i0, KP), sub, b);
+                                const T x = (T)(u ? xf1 : xf0);
                                 const T s = group_dot<T, KL, LPC>(tm, b);
                                 if (MODE == MODE_PHI) {
                                     const bool ok = s >= tiny;
@@ -575,8 +608,7 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
         if (w + 1 < w1) {   // prime the ring for the next window before its staging barrier
             steps = __builtin_amdgcn_readfirstlane((int)st[w + 1]);
 #pragma unroll
-            for (int i = 0; i < RING; ++i)
-                if (i < steps) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
+            for (int i = 0; i < RING; ++i) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
         }
     }
 
