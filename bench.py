@@ -245,7 +245,10 @@ def main():
     b_iter = algorithmic_bytes(nnz_local, n_local, G, K, itemsize)
     sweeps = prof["cell_sweep"]["launches"] + prof["gene_sweep"]["launches"]
     sweep_ms = (prof["cell_sweep"]["ms"] + prof["gene_sweep"]["ms"]) / max(sweeps, 1)
-    achieved = (b_iter / 2.0) / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    # launches per iteration: 2 (cell-side + gene-side) or 1 (both sides in one dual launch)
+    per_iter = max(1, int(round(sweeps / float(args.steps))))
+    b_launch = b_iter / per_iter
+    achieved = b_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     info = eng.plan_info()
     # HBM bytes per launch from the committed rocprofv3 PMC passes (collected separately, as PMC
     # must be; profiles/r01/pmc_traffic.json), only for the configuration they were taken on
@@ -275,11 +278,14 @@ def main():
             "plan": info,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "sweep_kernel (cell + gene launches; algorithmic bytes per "
-                                      "launch = B_iter/2, B_iter = 12*nnz + 4*K*s*(N+G) + 2*s*(N+G))",
+            "bound": "hbm",
+            "kernel": ("tile_sweep_dual_kernel (cell-side + gene-side sweep in one launch; algorithmic "
+                       "bytes per launch = B_iter" if per_iter == 1 else
+                       "tile_sweep_kernel (cell + gene launches; algorithmic bytes per launch = B_iter/2")
+                      + ", B_iter = 12*nnz + 4*K*s*(N+G) + 2*s*(N+G))",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_gb_per_launch": b_iter / 2.0 / 1e9,
+            "algorithmic_gb_per_launch": b_launch / 1e9, "sweep_launches_per_iteration": per_iter,
             "avg_launch_ms": sweep_ms, "launches": sweeps,
             "cell_sweep_ms": prof["cell_sweep"]["ms"] / max(prof["cell_sweep"]["launches"], 1),
             "gene_sweep_ms": prof["gene_sweep"]["ms"] / max(prof["gene_sweep"]["launches"], 1),

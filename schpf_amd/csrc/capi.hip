@@ -112,8 +112,7 @@ struct PlanDev {
 
 struct TileDev {
     schpf::TilePlanHost host;   // entries/steps cleared after upload; order/mptr kept
-    DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, task_wave_end, pfirst, pcount,
-        partials;
+    DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, pfirst, pcount, partials;
     int64_t n_tasks = 0, entry_slots = 0, n_wave_out = 0;
     int threads = 512;
     size_t lds_bytes = 0;
@@ -188,6 +187,8 @@ template <typename T> struct Engine final : schpf_ctx {
     DevBuf wave_out, scalars;                       // llh per wave; scalars[0]=llh sum
     PlanDev cell, gene;                             // gather plans: major = cell / major = gene
     TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
+    DevBuf dual_order;                              // merged launch order of both plans' tasks (or empty)
+    int64_t dual_slots = 0;
     bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
     double gammaln_sum = 0.0;
@@ -314,7 +315,6 @@ template <typename T> struct Engine final : schpf_ctx {
         upload(td.task_w0, h.task_w0, stream);
         upload(td.task_w1, h.task_w1, stream);
         upload(td.task_wave_off, h.task_wave_off, stream);
-        upload(td.task_wave_end, h.task_wave_end, stream);
         upload(td.pfirst, h.pfirst, stream);
         upload(td.pcount, h.pcount, stream);
         td.partials.alloc((size_t)std::max<int64_t>(h.n_partial_rows, 1) * KP * sizeof(T), true, stream);
@@ -325,7 +325,6 @@ template <typename T> struct Engine final : schpf_ctx {
         std::vector<uint32_t>().swap(h.entries);
         std::vector<uint16_t>().swap(h.steps);
         std::vector<int64_t>().swap(h.task_wave_off);
-        std::vector<int64_t>().swap(h.task_wave_end);
     }
 
     // Workgroup shape of the tile sweep.  Big problems: one 1024-thread workgroup per CU with a
@@ -381,6 +380,25 @@ template <typename T> struct Engine final : schpf_ctx {
         if (err) std::rethrow_exception(err);
         upload_tile(tcell, secs_cell);
         upload_tile(tgene, secs_gene);
+        // Both sweeps of an iteration in one launch (kernels.h launch_tile_sweep_dual) when the two
+        // plans agree on the workgroup shape: slots = all tasks of both plans, longest first
+        dual_slots = 0;
+        dual_order.release();
+        if (env_int("SCHPF_DUAL", 1) && tcell.threads == tgene.threads && tcell.packed == tgene.packed) {
+            const auto &hc = tcell.host, &hg = tgene.host;
+            std::vector<int32_t> ord;
+            ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
+            size_t i = 0, j = 0;   // merge of two lists already sorted by decreasing work
+            while (i < hc.task_order.size() || j < hg.task_order.size()) {
+                const bool take_cell = j >= hg.task_order.size() ||
+                    (i < hc.task_order.size() &&
+                     hc.task_work[(size_t)hc.task_order[i]] >= hg.task_work[(size_t)hg.task_order[j]]);
+                if (take_cell) ord.push_back(hc.task_order[i++]);
+                else ord.push_back(~hg.task_order[j++]);
+            }
+            dual_slots = (int64_t)ord.size();
+            if (dual_slots > 0) { upload(dual_order, ord, stream); HIPCHK(hipStreamSynchronize(stream)); }
+        }
     }
 
     static double now_s()
@@ -582,7 +600,7 @@ template <typename T> struct Engine final : schpf_ctx {
         a.task_w0 = td.task_w0.as<int>();
         a.task_w1 = td.task_w1.as<int>();
         a.task_wave_off = td.task_wave_off.as<int64_t>();
-        a.task_wave_end = td.task_wave_end.as<int64_t>();
+        a.task_order = nullptr;   // natural order (plan.cpp)
         a.tab_major = tab_major.as<T>();
         a.tab_minor = tab_minor.as<T>();
         a.log_major = log_major.as<T>();
@@ -673,7 +691,17 @@ template <typename T> struct Engine final : schpf_ctx {
         const bool sharded = flags_ & SCHPF_SHARDED;
         const bool only_gene = flags_ & SCHPF_LOCAL_GENE, only_cell = flags_ & SCHPF_LOCAL_CELL;
         const bool do_cell = !only_gene || only_cell, do_gene = !only_cell || only_gene;
-        if (pending_init == 0) {
+        if (pending_init == 0 && use_tile && dual_slots > 0 && do_gene && do_cell && !freeze) {
+            // both sweeps read the same old tables: one launch (timed as kind 0, see schpf_profile_read)
+            ScopedTimer tm(prof, stream, 0);
+            auto ac = tile_args(tcell, th_exp, be_exp, th_log, be_log, G);
+            auto ag = tile_args(tgene, be_exp, th_exp, be_log, th_log, N);
+            ac.major_is_cell = 1; ag.major_is_cell = 0;
+            HIPCHK(schpf::launch_tile_sweep_dual<T>(ac, ag, dual_order.as<int>(), NV, LPC, tcell.packed ? 1 : 0,
+                                                    dual_slots, tcell.threads, std::max(tcell.lds_bytes, tgene.lds_bytes),
+                                                    stream));
+            tm.stop();
+        } else if (pending_init == 0) {
             if (do_gene && !freeze) {
                 ScopedTimer tm(prof, stream, 1);
                 run_sweep(1, schpf::MODE_PHI);

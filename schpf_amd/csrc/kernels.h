@@ -32,7 +32,7 @@ template <typename T> struct TileArgs {
     const int *block_rows;         // [n_blocks * gpb]
     const int *task_block, *task_w0, *task_w1;
     const int64_t *task_wave_off;  // [task * wpb + wave] first uint4 of the wave's entries in the task
-    const int64_t *task_wave_end;  // [task * wpb + wave] one past its last
+    const int *task_order;         // [launch slot] -> task (longest first); nullptr = identity
     const T *tab_major;            // [n_major, KP]
     const T *tab_minor;            // [n_minor, KP]  (staged window by window)
     const T *log_major, *log_minor;
@@ -69,6 +69,10 @@ hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t se
 template <typename T>
 hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int packed, int64_t n_tasks,
                              int threads, size_t lds_bytes, hipStream_t st);
+// cell-side (a0) and gene-side (a1) MODE_PHI sweeps in one launch; order[slot] = task | ~task
+template <typename T>
+hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
+                                  int packed, int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);

@@ -384,6 +384,29 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     for (int e : err)
         if (e) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
 
+    // work of a task: its workgroup runs, window by window, as long as its slowest wave (+ a
+    // staging of the window).  task_order (longest first) is the order of the merged cell+gene
+    // launch; a single-plan launch keeps the natural order (neighbouring workgroups then stage
+    // the same windows, which measured ~3 % faster than longest-first)
+    P.task_work.assign((size_t)P.n_tasks, 0);
+    parallel_for(P.n_tasks, nth, [&](int64_t t0_, int64_t t1_, int) {
+        for (int64_t t = t0_; t < t1_; ++t) {
+            const int64_t b = P.task_block[(size_t)t];
+            int64_t work = 0;
+            for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
+                int mx = 0;
+                for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, P.steps[((size_t)b * wpb + v) * W + w]);
+                work += mx + 2;
+            }
+            P.task_work[(size_t)t] = work;
+        }
+    });
+    P.task_order.resize((size_t)P.n_tasks);
+    std::iota(P.task_order.begin(), P.task_order.end(), 0);
+    std::stable_sort(P.task_order.begin(), P.task_order.end(), [&](int32_t x, int32_t y) {
+        return P.task_work[(size_t)x] > P.task_work[(size_t)y];
+    });
+
     const double t3 = now();
     std::vector<int64_t> wave_off((size_t)P.n_blocks * wpb + 1, 0);   // entries of (block, wave), window order
     for (size_t bw = 0; bw < (size_t)P.n_blocks * wpb; ++bw) {
@@ -415,7 +438,6 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
     P.task_wave_off.resize((size_t)P.n_tasks * wpb);
-    P.task_wave_end.resize((size_t)P.n_tasks * wpb);
     // fill: walk each row's nonzeros in minor order; position inside its window segment = t
     // rank of every group of a wave inside its ds_read_b128 pass (16 lanes served per LDS cycle)
     std::vector<int> pass_rank((size_t)gpw, 0);
@@ -441,7 +463,6 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                     const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
                     if (w % wpt == 0) P.task_wave_off[tv] = off;
                     off += (int64_t)P.steps[bw * W + w] * gpw;
-                    P.task_wave_end[tv] = off;
                 }
             }
             for (int g = 0; g < gpb; ++g) {

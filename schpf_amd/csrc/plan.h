@@ -87,7 +87,9 @@ struct TilePlanHost {
     std::vector<uint16_t> steps;
     std::vector<int32_t> block_rows;      // [n_blocks * gpb] major id or -1
     std::vector<int32_t> task_block, task_w0, task_w1;
-    std::vector<int64_t> task_wave_off, task_wave_end;
+    std::vector<int64_t> task_wave_off;
+    std::vector<int64_t> task_work;    // [task] wave-steps the task's workgroup sits through (barrier-limited)
+    std::vector<int32_t> task_order;   // tasks by decreasing work (launch order of the merged cell+gene launch)
     std::vector<int32_t> pfirst, pcount;  // [n_major]
     std::vector<int32_t> order;           // [nnz] (major, minor)-sorted position -> caller's COO position
     std::vector<int64_t> mptr;            // [n_major + 1]

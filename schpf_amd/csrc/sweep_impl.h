@@ -459,10 +459,9 @@ template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
 // The entry stream runs through a 4-slot register ring: slot i is refilled with step p+4 as
 // soon as step p has been taken out of it, and the ring for the NEXT window is primed before
 // that window's staging barrier, so HBM latency hides behind four steps of math or a staging.
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
-__global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
+template <typename T, int NV, int LPC, int MODE, bool PACK>
+__device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
-    typedef typename Vec16<T>::type V;
     typedef TileEntry<PACK> EF;
     typedef typename EF::type E;
     constexpr int VEC = Vec16<T>::N;
@@ -473,7 +472,6 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *win = reinterpret_cast<T *>(lds_raw);
 
-    const int task = blockIdx.x;
     const int blk = a.task_block[task], w0 = a.task_w0[task], w1 = a.task_w1[task];
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int grp = lane / LPC, sub = lane % LPC;
@@ -634,6 +632,26 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
     store_lane<T, NV, LPC>(out_row, sub, acc);
 }
 
+// launch slot -> task: longest tasks first (plan.h task_order), so the launch has a short tail
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
+__global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
+{
+    const int task = a.task_order ? a.task_order[blockIdx.x] : (int)blockIdx.x;
+    tile_sweep_task<T, NV, LPC, MODE, PACK>(a, task);
+}
+// Both sweeps of an iteration in ONE launch (they read the same old tables and write disjoint
+// partials): order[slot] = task of the cell-side plan, or ~task of the gene-side plan, merged
+// longest-first.  One launch has one tail instead of two and the two task pools fill each
+// other's idle compute units.
+template <typename T, int NV, int LPC, int MAXT, bool PACK>
+__global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
+                                                              const int *__restrict__ order)
+{
+    const int code = order[blockIdx.x];
+    if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, PACK>(a0, code);
+    else tile_sweep_task<T, NV, LPC, MODE_PHI, PACK>(a1, ~code);
+}
+
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 static hipError_t launch_tile_b(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
@@ -670,6 +688,35 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
                       : launch_tile_b<T, NV, LPC, 512, false>(a, mode, n_tasks, threads, lds_bytes, st);
     return packed ? launch_tile_b<T, NV, LPC, 1024, true>(a, mode, n_tasks, threads, lds_bytes, st)
                   : launch_tile_b<T, NV, LPC, 1024, false>(a, mode, n_tasks, threads, lds_bytes, st);
+}
+
+template <typename T, int NV, int LPC, int MAXT, bool PACK>
+static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
+                                int threads, size_t lds_bytes, hipStream_t st)
+{
+    if (lds_bytes > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>), dim3((unsigned)n_slots),
+                       dim3((unsigned)threads), lds_bytes, st, a0, a1, order);
+    return hipGetLastError();
+}
+template <typename T, int NV, int LPC>
+static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int packed,
+                                int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st)
+{
+    if (n_slots == 0) return hipSuccess;
+    if (threads <= 512)
+        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, st)
+                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, st);
+    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, st)
+                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, st);
 }
 
 // ------------------------------------------------------------------------ launchers
@@ -733,6 +780,13 @@ hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, in
                              int threads, size_t lds_bytes, hipStream_t st)
 {
     SCHPF_DISPATCH(nv, lpc, (launch_tile_t<T, NV, LPC>(a, mode, packed, n_tasks, threads, lds_bytes, st)))
+}
+
+template <typename T>
+hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
+                                  int packed, int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st)
+{
+    SCHPF_DISPATCH(nv, lpc, (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, st)))
 }
 
 }  // namespace schpf
