@@ -303,11 +303,17 @@ def main():
         out["cpu_baseline"] = cpu_baseline(X, K, dtype)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     eng.close()
     if sharded:
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a
+    # pipe: flush it now so that the JSON line is the LAST line of stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -502,9 +502,27 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
             }
         }
     });
-    if (verbose)
+    if (verbose) {
         fprintf(stderr, "[schpf_hip]     sort %.3f s, sorted copies %.3f s, steps %.3f s, alloc+fill %.3f s\n", t1 - t0,
                 t2 - t1, t3 - t2, now() - t3);
+        // where the stored slots go: nonzeros / sliced-ELL padding inside a wave / waiting at the
+        // window barrier for the slowest wave of the workgroup
+        int64_t wave_steps = 0, barrier_steps = 0;
+        for (int64_t b = 0; b < P.n_blocks; ++b)
+            for (int w = 0; w < W; ++w) {
+                int mx = 0;
+                for (int v = 0; v < wpb; ++v) {
+                    const int s = P.steps.empty() ? 0 : P.steps[((size_t)b * wpb + v) * W + w];
+                    wave_steps += s;
+                    mx = std::max(mx, s);
+                }
+                barrier_steps += (int64_t)mx * wpb;
+            }
+        fprintf(stderr, "[schpf_hip]     nnz %lld, step slots x2 %lld (ELL fill %.3f), barrier-limited wave-steps %lld vs %lld "
+                "(%.3f)\n", (long long)nnz, (long long)(wave_steps * gpw * 2),
+                wave_steps ? (double)nnz / (double)(wave_steps * gpw * 2) : 0.0, (long long)barrier_steps,
+                (long long)wave_steps, wave_steps ? (double)wave_steps / (double)barrier_steps : 0.0);
+    }
     if (keep_order) {
         P.order.swap(order);
         P.mptr.swap(mptr);

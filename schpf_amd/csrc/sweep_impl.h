@@ -123,8 +123,7 @@ __device__ __forceinline__ double fast_div(double x, double s)
 }
 __device__ __forceinline__ float fast_div(float x, float s)
 {
-    float r = __builtin_amdgcn_rcpf(s);
-    r = fmaf(fmaf(-s, r, 1.0f), r, r);
+    const float r = __builtin_amdgcn_rcpf(s);   // 1 ulp; the residual correction below restores <= 1 ulp in q
     const float q = x * r;
     return fmaf(fmaf(-s, q, x), r, q);
 }
@@ -487,6 +486,10 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     double llh = 0.0;
     bool any_bad = false;
     const T tiny = Vec16<T>::tiny();
+    constexpr bool PAIR = KL * (int)sizeof(T) <= 96;   // narrow rows: two minor rows in registers
+    constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
+    T bA[KL], bB[KL];                                  // PIPE: the rows of the step being / about to be computed
+    float xa = 0.f, xb = 0.f;                          //       and that step's counts
 
     // position (in step slots) of this group's entries; advances window by window
     size_t pos = (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp;
@@ -518,6 +521,71 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
             }
             __syncthreads();
         }
+        if (PIPE) {
+            // Rolling LDS pipeline, one nonzero deep: the minor rows of step p+1 are fetched from the
+            // window while step p is still being computed -- row A' right after nonzero A has been
+            // consumed, into the same registers, then the same for B.  A wave never starts a step
+            // by waiting a full LDS latency (measured: the unpipelined loop overlapped the LDS read
+            // phase and the FMA phase of the 4 waves of a SIMD poorly).
+            if (steps > 0) {   // prologue: the first step's rows (the ring was primed before the barrier)
+                const E c = ring[0];
+                unsigned i0 = EF::idx(c, 0), i1 = EF::idx(c, 1);
+                xa = EF::val(c, 0); xb = EF::val(c, 1);
+                asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xa), "+v"(xb));
+                load_lane<T, NV, LPC>(win + __umul24(i0, KP), sub, bA);
+                load_lane<T, NV, LPC>(win + __umul24(i1, KP), sub, bB);
+            }
+            for (int p = 0; p < steps; p += RING) {
+#pragma unroll
+                for (int i = 0; i < RING; ++i) {
+                    // slot i was decoded one step ago: refill it; decode the NEXT step's slot.  Past the
+                    // window's last step that is the next window's entry or padding: its indices
+                    // are in range, the rows read with them are never used
+                    ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
+                    if (p + i < steps) {                               // scalar branch
+                        const E cn = ring[(i + 1) % RING];
+                        unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
+                        float nx0 = EF::val(cn, 0), nx1 = EF::val(cn, 1);
+                        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(nx0), "+v"(nx1));
+                        const T x0 = (T)xa, x1 = (T)xb;
+                        const T s0 = group_dot<T, KL, LPC>(tm, bA);
+                        if (MODE == MODE_PHI) {
+                            const bool ok0 = s0 >= tiny;
+                            const T q0 = safe_weight(x0, s0, ok0);
+                            any_bad |= x0 > T(0) && !ok0;
+#pragma unroll
+                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
+                        }
+                        load_lane<T, NV, LPC>(win + __umul24(n0, KP), sub, bA);
+                        // nothing moves across: row A' must be requested BEFORE nonzero B is computed
+                        __builtin_amdgcn_sched_barrier(0);
+                        const T s1 = group_dot<T, KL, LPC>(tm, bB);
+                        if (MODE == MODE_PHI) {
+                            const bool ok1 = s1 >= tiny;
+                            const T q1 = safe_weight(x1, s1, ok1);
+                            any_bad |= x1 > T(0) && !ok1;
+#pragma unroll
+                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
+                        }
+                        load_lane<T, NV, LPC>(win + __umul24(n1, KP), sub, bB);
+                        if (MODE == MODE_LLH) {
+                            if (LPC == 1) {
+                                if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
+                                if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
+                            } else {
+                                // every lane of the group knows s0 and s1: lane 0 takes the log of the
+                                // first nonzero, lane 1 of the second (the f64 log is the costly part)
+                                const T sm = (sub & 1) ? s1 : s0;
+                                const T xm = (sub & 1) ? x1 : x0;
+                                if (sub < 2 && xm > T(0)) llh += (double)xm * log((double)sm) - (double)sm;
+                            }
+                        }
+                        xa = nx0; xb = nx1;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else
         for (int p = 0; p < steps; p += RING) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) {
@@ -553,7 +621,6 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         }
                     } else {
                         // narrow rows: both nonzeros of the step in flight; wide rows: one at a time
-                        constexpr bool PAIR = KL * (int)sizeof(T) <= 96;
                         if (PAIR) {
                             T b0[KL], b1[KL];
                             load_lane<T, NV, LPC>(win + __umul24(i0, KP), sub, b0);
@@ -612,8 +679,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
 
     if (MODE == MODE_LLH) {
         // which lanes hold a share: all (LPC 1), lanes 0-1 of a group (paired steps), lane 0 (else)
-        constexpr bool PAIRED = KL * (int)sizeof(T) <= 96;
-        if (LPC > 1 && !(PAIRED ? sub < 2 : sub == 0)) llh = 0.0;
+        if (LPC > 1 && !(PAIR ? sub < 2 : sub == 0)) llh = 0.0;
         llh = wave_sum(llh);
         if (lane == 0) a.wave_out[(size_t)task * a.wpb + wv] = llh;
         return;
