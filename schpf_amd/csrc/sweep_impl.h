@@ -76,12 +76,12 @@ template <typename T, int LPC> __device__ __forceinline__ int factor_of(int r, i
 // row_half_mirror (i <-> 7-i) and row_mirror (i <-> 15-i) complete an all-reduce over 16 lanes.
 template <int STEP> __device__ __forceinline__ int dpp_partner(int v)
 {
-    // every lane has a valid source under these patterns, so the `old` operand is never used;
-    // passing v itself spares the v_mov that would zero-initialise the destination
-    if (STEP == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    if (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    if (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false);                 // row_mirror
+    // every lane has a valid source under these patterns; mov_dpp (no `old` operand) spares the
+    // copies / zero-initialisation that update_dpp needs for its tied destination
+    if (STEP == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    if (STEP == 1) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    if (STEP == 2) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);                 // row_mirror
 }
 template <int STEP> __device__ __forceinline__ float partner(float v)
 {
@@ -552,7 +552,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         if (MODE == MODE_PHI) {
                             const bool ok0 = s0 >= tiny;
                             const T q0 = safe_weight(x0, s0, ok0);
-                            any_bad |= x0 > T(0) && !ok0;
+                            any_bad |= !ok0;   // padding slots included (x = 0): a spurious trip to the cold path is harmless
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
                         }
@@ -563,7 +563,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         if (MODE == MODE_PHI) {
                             const bool ok1 = s1 >= tiny;
                             const T q1 = safe_weight(x1, s1, ok1);
-                            any_bad |= x1 > T(0) && !ok1;
+                            any_bad |= !ok1;
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
                         }
@@ -685,7 +685,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
         return;
     }
     T *out_row = a.partials + ((size_t)task * gpb + g) * KP;
-    if (MODE == MODE_PHI && __builtin_expect(any_bad, 0)) {   // group-uniform; rare: see slow_nonzero
+    if (MODE == MODE_PHI && __builtin_expect(any_bad && live, 0)) {   // group-uniform; rare: see slow_nonzero
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
                                         a.win_rows, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K, out_row);
         return;
