@@ -156,7 +156,9 @@ int schpf_synchronize(schpf_ctx *ctx);
 
 /* HIP-event timing of the sweep kernel launches on the context's stream (bench.py).
  * ms[0] = cell sweep, ms[1] = gene sweep, ms[2] = loss sweep, ms[3] = gamma updates;
- * launches[] likewise.  Reading synchronises the stream and resets the counters. */
+ * launches[] likewise.  When both sweeps of an iteration run as ONE launch (the default for
+ * schpf_step) that launch is counted under ms[0]/launches[0] and ms[1] stays 0.
+ * Reading synchronises the stream and resets the counters. */
 int schpf_profile_enable(schpf_ctx *ctx, int enable);
 int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
 

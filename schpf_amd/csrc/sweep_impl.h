@@ -489,7 +489,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     constexpr bool PAIR = KL * (int)sizeof(T) <= 96;   // narrow rows: two minor rows in registers
     constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
     T bA[KL], bB[KL];                                  // PIPE: the rows of the step being / about to be computed
-    float xa = 0.f, xb = 0.f;                          //       and that step's counts
+    float xc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};         //       counts of that step [step parity][nonzero]
 
     // position (in step slots) of this group's entries; advances window by window
     size_t pos = (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp;
@@ -530,8 +530,8 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
             if (steps > 0) {   // prologue: the first step's rows (the ring was primed before the barrier)
                 const E c = ring[0];
                 unsigned i0 = EF::idx(c, 0), i1 = EF::idx(c, 1);
-                xa = EF::val(c, 0); xb = EF::val(c, 1);
-                asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xa), "+v"(xb));
+                xc[0][0] = EF::val(c, 0); xc[0][1] = EF::val(c, 1);
+                asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xc[0][0]), "+v"(xc[0][1]));
                 load_lane<T, NV, LPC>(win + __umul24(i0, KP), sub, bA);
                 load_lane<T, NV, LPC>(win + __umul24(i1, KP), sub, bB);
             }
@@ -545,14 +545,17 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                     if (p + i < steps) {                               // scalar branch
                         const E cn = ring[(i + 1) % RING];
                         unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
-                        float nx0 = EF::val(cn, 0), nx1 = EF::val(cn, 1);
-                        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(nx0), "+v"(nx1));
-                        const T x0 = (T)xa, x1 = (T)xb;
+                        // counts alternate between two register pairs (RING is even), no copies
+                        xc[(i + 1) & 1][0] = EF::val(cn, 0); xc[(i + 1) & 1][1] = EF::val(cn, 1);
+                        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(xc[(i + 1) & 1][0]), "+v"(xc[(i + 1) & 1][1]));
+                        const T x0 = (T)xc[i & 1][0], x1 = (T)xc[i & 1][1];
                         const T s0 = group_dot<T, KL, LPC>(tm, bA);
                         if (MODE == MODE_PHI) {
-                            const bool ok0 = s0 >= tiny;
-                            const T q0 = safe_weight(x0, s0, ok0);
-                            any_bad |= !ok0;   // padding slots included (x = 0): a spurious trip to the cold path is harmless
+                            // no masking of an underflowed normaliser: whatever reaches the accumulators
+                            // then (inf, NaN) is discarded, because ANY slot of the group with s < tiny
+                            // -- padding slots (x = 0) included -- sends the group to the cold path
+                            const T q0 = fast_div(x0, s0);
+                            any_bad |= !(s0 >= tiny);
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
                         }
@@ -561,9 +564,8 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         __builtin_amdgcn_sched_barrier(0);
                         const T s1 = group_dot<T, KL, LPC>(tm, bB);
                         if (MODE == MODE_PHI) {
-                            const bool ok1 = s1 >= tiny;
-                            const T q1 = safe_weight(x1, s1, ok1);
-                            any_bad |= !ok1;
+                            const T q1 = fast_div(x1, s1);
+                            any_bad |= !(s1 >= tiny);
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
                         }
@@ -580,7 +582,6 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                                 if (sub < 2 && xm > T(0)) llh += (double)xm * log((double)sm) - (double)sm;
                             }
                         }
-                        xa = nx0; xb = nx1;
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -692,7 +693,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     }
     if (MODE == MODE_PHI) {
 #pragma unroll
-        for (int k = 0; k < KL; ++k) acc[k] *= tm[k];
+        for (int k = 0; k < KL; ++k) acc[k] = live ? acc[k] * tm[k] : T(0);
     }
     // dead groups write zeros too: every partial row of the task is defined after a sweep
     store_lane<T, NV, LPC>(out_row, sub, acc);

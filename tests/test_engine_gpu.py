@@ -450,3 +450,25 @@ def test_skewed_expression_matrix_matches_oracle(amd, oracle):
             want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
                                                  st.beta_shape, st.beta_rate)
             assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, monkeypatch):
+    """One launch for both orientations (tile_sweep_dual_kernel) runs the same tasks with the same
+    fixed-order reductions as one launch per orientation: identical bits, and run-to-run
+    deterministic (no atomics anywhere)."""
+    if plan_kind != "tile":
+        pytest.skip("the gather plan has no dual launch")
+    X = synthetic_counts(3000, 2500, 0.04, seed=5)
+    K = 20
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=2)
+    results = []
+    for dual in ("1", "0", "1"):
+        monkeypatch.setenv("SCHPF_DUAL", dual)
+        with load_engine(amd, X, K, dtype, st, 0.3, 0.3, bp, dp) as eng:
+            for _ in range(3):
+                eng.step()
+            results.append([eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")])
+    for other in results[1:]:
+        for (s0, r0), (s1, r1) in zip(results[0], other):
+            assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
