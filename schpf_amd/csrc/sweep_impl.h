@@ -110,20 +110,30 @@ template <typename T, int LPC> __device__ __forceinline__ T group_max(T v)
     return v;
 }
 
-// x / s for s known to be a normal positive number: hardware reciprocal + Newton steps instead
-// of the IEEE division sequence (no scaling / fix-up needed here).  <= 2 ulp: v_rcp_f64 is good
-// to ~2^-24, one Newton step squares that (2^-48), and the residual correction of the quotient
-// multiplies the two errors (rounding level).
+// x / s for s known to be a normal positive number: hardware reciprocal (+ one Newton step in
+// f64) instead of the IEEE division sequence -- no scaling / fix-up is needed here.
+//   f64: v_rcp_f64 is good to ~2^-24, the Newton step squares that: relative error <= ~2^-48
+//        (4e-15) per weight, three orders of magnitude below the tightest parity tolerance
+//        (1e-12) and of random sign, so it averages out in the sums over a row's nonzeros;
+//   f32: v_rcp_f32 is good to 1 ulp: x * rcp(s) is within 2 ulp.
+// fast_div_exact keeps the residual correction (<= 1 ulp) for the paths that are not VALU-bound.
 __device__ __forceinline__ double fast_div(double x, double s)
+{
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
+    return x * r;
+}
+__device__ __forceinline__ float fast_div(float x, float s) { return x * __builtin_amdgcn_rcpf(s); }
+__device__ __forceinline__ double fast_div_exact(double x, double s)
 {
     double r = __builtin_amdgcn_rcp(s);
     r = fma(fma(-s, r, 1.0), r, r);
     const double q = x * r;
     return fma(fma(-s, q, x), r, q);
 }
-__device__ __forceinline__ float fast_div(float x, float s)
+__device__ __forceinline__ float fast_div_exact(float x, float s)
 {
-    const float r = __builtin_amdgcn_rcpf(s);   // 1 ulp; the residual correction below restores <= 1 ulp in q
+    const float r = __builtin_amdgcn_rcpf(s);
     const float q = x * r;
     return fmaf(fmaf(-s, q, x), r, q);
 }
@@ -141,7 +151,7 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return fmaf(
 // (ok == false) the quotient is inf/NaN garbage and is masked -- the cold path redoes that group.
 template <typename T> __device__ __forceinline__ T safe_weight(T x, T s, bool ok)
 {
-    const T q = fast_div(x, s);
+    const T q = fast_div_exact(x, s);
     return ok ? q : T(0);
 }
 
