@@ -468,7 +468,7 @@ template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
 // The entry stream runs through a 4-slot register ring: slot i is refilled with step p+4 as
 // soon as step p has been taken out of it, and the ring for the NEXT window is primed before
 // that window's staging barrier, so HBM latency hides behind four steps of math or a staging.
-template <typename T, int NV, int LPC, int MODE, bool PACK>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
     typedef TileEntry<PACK> EF;
@@ -496,7 +496,8 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     double llh = 0.0;
     bool any_bad = false;
     const T tiny = Vec16<T>::tiny();
-    constexpr bool PAIR = KL * (int)sizeof(T) <= 96;   // narrow rows: two minor rows in registers
+    // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
+    constexpr bool PAIR = KL * (int)sizeof(T) <= (MAXT <= 512 ? 192 : 96);
     constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
     T bA[KL], bB[KL];                                  // PIPE: the rows of the step being / about to be computed
     float xc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};         //       counts of that step [step parity][nonzero]
@@ -714,7 +715,7 @@ template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
     const int task = a.task_order ? a.task_order[blockIdx.x] : (int)blockIdx.x;
-    tile_sweep_task<T, NV, LPC, MODE, PACK>(a, task);
+    tile_sweep_task<T, NV, LPC, MODE, MAXT, PACK>(a, task);
 }
 // Both sweeps of an iteration in ONE launch (they read the same old tables and write disjoint
 // partials): order[slot] = task of the cell-side plan, or ~task of the gene-side plan, merged
@@ -725,8 +726,8 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, T
                                                               const int *__restrict__ order)
 {
     const int code = order[blockIdx.x];
-    if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, PACK>(a0, code);
-    else tile_sweep_task<T, NV, LPC, MODE_PHI, PACK>(a1, ~code);
+    if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a0, code);
+    else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a1, ~code);
 }
 
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
