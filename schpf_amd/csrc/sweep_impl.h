@@ -562,11 +562,12 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         const T x0 = (T)xc[i & 1][0], x1 = (T)xc[i & 1][1];
                         const T s0 = group_dot<T, KL, LPC>(tm, bA);
                         if (MODE == MODE_PHI) {
-                            // no masking of an underflowed normaliser: whatever reaches the accumulators
-                            // then (inf, NaN) is discarded, because ANY slot of the group with s < tiny
-                            // -- padding slots (x = 0) included -- sends the group to the cold path
+                            // no test of the normaliser here: a product-form s that underflowed (zero /
+                            // denormal) makes the reciprocal inf, and inf * b or 0 * inf poisons EVERY
+                            // accumulator of every lane of the group (inf or NaN) -- detected once, after
+                            // the task, and the group is then redone by the cold path.  A small but
+                            // normal s is exact enough: its largest term is a normal number.
                             const T q0 = fast_div(x0, s0);
-                            any_bad |= !(s0 >= tiny);
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
                         }
@@ -576,7 +577,6 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         const T s1 = group_dot<T, KL, LPC>(tm, bB);
                         if (MODE == MODE_PHI) {
                             const T q1 = fast_div(x1, s1);
-                            any_bad |= !(s1 >= tiny);
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
                         }
@@ -697,6 +697,12 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
         return;
     }
     T *out_row = a.partials + ((size_t)task * gpb + g) * KP;
+    if (MODE == MODE_PHI && PIPE) {   // non-finite accumulators <=> some normaliser underflowed (see the loop)
+        T probe = T(0);
+#pragma unroll
+        for (int k = 0; k < KL; ++k) probe = fma_t(acc[k], T(0), probe);   // 0, or NaN
+        any_bad = !(probe == T(0));
+    }
     if (MODE == MODE_PHI && __builtin_expect(any_bad && live, 0)) {   // group-uniform; rare: see slow_nonzero
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
                                         a.win_rows, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K, out_row);
