@@ -166,6 +166,13 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
  * n_chunks_cell, n_chunks_gene, n_waves_cell, n_waves_gene, stored entry slots cell, gene */
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]);
 
+/* Row sums (per cell) and column sums (per gene) of a host COO matrix: the inputs of the empirical
+ * hyperparameters bp = ap * mean/var(cell sums), dp = cp * mean/var(gene sums)
+ * (scHPF_.py:847-879, where they are X.sum(1) / X.sum(0)).  Host-side, multi-threaded, no GPU
+ * needed; sums are accumulated in double (exact for counts).  row_sums[ncells], col_sums[ngenes]. */
+int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int val_kind,
+                        int ncells, int ngenes, double *row_sums, double *col_sums);
+
 /* Test hook (host only, no GPU needed): build one sweep plan from (major, minor, val) and expand
  * it back into per-nonzero records in storage order -- the major/minor/val it will be processed
  * with, the partials row (natural chunk id) it accumulates into and the wavefront that streams

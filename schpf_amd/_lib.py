@@ -50,6 +50,7 @@ SIGNATURES = {
     "schpf_profile_enable": [_vp, _int],
     "schpf_profile_read": [_vp, _dblp, _i64p],
     "schpf_plan_info": [_vp, _i64p],
+    "schpf_coo_marginals": [_i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp],
     "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64p],
     "schpf_debug_tile_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,

@@ -1106,6 +1106,49 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
 }
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]) { CTX_CALL(ctx->plan_info(info)); }
 
+int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind,
+                        int ncells, int ngenes, double *row_sums, double *col_sums)
+{
+    return guarded([&] {
+        if (nnz < 0 || ncells < 0 || ngenes < 0) throw std::invalid_argument("negative size");
+        if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
+        // per-thread partial sums over contiguous slabs, added up in thread order: exact for counts
+        // (integers far below 2^53) and run-to-run deterministic for anything else
+        const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(schpf::host_threads(), 16), nnz / 65536 + 1));
+        std::vector<std::vector<double>> pr((size_t)nth), pc((size_t)nth);
+        std::vector<int64_t> bad((size_t)nth, -1);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; ++t)
+            th.emplace_back([&, t] {
+                pr[(size_t)t].assign((size_t)ncells, 0.0);
+                pc[(size_t)t].assign((size_t)ngenes, 0.0);
+                double *r = pr[(size_t)t].data(), *g = pc[(size_t)t].data();
+                const int64_t b = nnz * t / nth, e = nnz * (t + 1) / nth;
+                for (int64_t i = b; i < e; ++i) {
+                    if (row[i] < 0 || row[i] >= ncells || col[i] < 0 || col[i] >= ngenes) {
+                        if (bad[(size_t)t] < 0) bad[(size_t)t] = i;
+                        continue;
+                    }
+                    double d;
+                    switch (kind) {
+                    case SCHPF_VAL_I32: d = (double)((const int32_t *)val)[i]; break;
+                    case SCHPF_VAL_I64: d = (double)((const int64_t *)val)[i]; break;
+                    case SCHPF_VAL_F32: d = (double)((const float *)val)[i]; break;
+                    default: d = ((const double *)val)[i]; break;
+                    }
+                    r[row[i]] += d;
+                    g[col[i]] += d;
+                }
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < nth; ++t)
+            if (bad[(size_t)t] >= 0)
+                throw std::invalid_argument("COO index out of range at entry " + std::to_string(bad[(size_t)t]));
+        for (int i = 0; i < ncells; ++i) { double s = 0.0; for (int t = 0; t < nth; ++t) s += pr[(size_t)t][(size_t)i]; row_sums[i] = s; }
+        for (int i = 0; i < ngenes; ++i) { double s = 0.0; for (int t = 0; t < nth; ++t) s += pc[(size_t)t][(size_t)i]; col_sums[i] = s; }
+    });
+}
+
 int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                             int n_major, int n_minor, int lpc, int chunk_len, int n_windows,
                             int32_t *out_major, int32_t *out_minor, float *out_val, int32_t *out_natid,

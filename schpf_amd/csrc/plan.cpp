@@ -80,7 +80,43 @@ void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vect
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
                          std::vector<int32_t> &order, std::vector<int64_t> &mptr)
 {
-    // minor first, then stable by major
+    // What order did the caller's COO come in?  SciPy's canonical format (sum_duplicates, tocoo of
+    // a CSR) is sorted by (row, col): the cell-side plan then needs no sort at all and the
+    // gene-side plan one stable pass.  One parallel scan decides.
+    const int nth = host_threads();
+    std::vector<char> not_mm((size_t)nth + 1, 0), not_nm((size_t)nth + 1, 0);
+    parallel_for(nnz, nth, [&](int64_t b, int64_t e, int t) {
+        bool bad_mm = false, bad_nm = false;
+        for (int64_t j = std::max<int64_t>(b, 1); j < e && !(bad_mm && bad_nm); ++j) {
+            const int32_t M0 = major[j - 1], M1 = major[j], m0 = minor[j - 1], m1 = minor[j];
+            bad_mm |= M1 < M0 || (M1 == M0 && m1 < m0);
+            bad_nm |= m1 < m0 || (m1 == m0 && M1 < M0);
+        }
+        not_mm[(size_t)t] = bad_mm;
+        not_nm[(size_t)t] = bad_nm;
+    });
+    bool sorted_mm = true, sorted_nm = true;
+    for (int t = 0; t <= nth; ++t) { sorted_mm = sorted_mm && !not_mm[(size_t)t]; sorted_nm = sorted_nm && !not_nm[(size_t)t]; }
+    if (sorted_mm) {
+        // identity order; run pointers from the positions where the major index changes
+        order.resize((size_t)nnz);
+        mptr.assign((size_t)n_major + 1, nnz);
+        for (int32_t k = 0; nnz > 0 && k <= major[0]; ++k) mptr[(size_t)k] = 0;
+        if (nnz == 0) std::fill(mptr.begin(), mptr.end(), 0);
+        parallel_for(nnz, nth, [&](int64_t b, int64_t e, int) {
+            for (int64_t j = b; j < e; ++j) {
+                order[(size_t)j] = (int32_t)j;
+                if (j > 0 && major[j] != major[j - 1])
+                    for (int32_t k = major[j - 1] + 1; k <= major[j]; ++k) mptr[(size_t)k] = j;
+            }
+        });
+        return;
+    }
+    if (sorted_nm) {   // already grouped by minor with ascending major inside: one stable pass by major
+        counting_sort_seq(nnz, nullptr, major, n_major, order, mptr);
+        return;
+    }
+    // general case: minor first, then stable by major
     std::vector<int32_t> by_minor;
     std::vector<int64_t> tmp_ptr;
     counting_sort_seq(nnz, nullptr, minor, n_minor, by_minor, tmp_ptr);

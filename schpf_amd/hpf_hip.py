@@ -17,7 +17,7 @@ from . import _lib
 
 __all__ = ["psi", "cgammaln", "compute_pois_llh", "compute_Xphi_data",
            "compute_loading_shape_update", "compute_loading_rate_update",
-           "compute_capacity_rate_update"]
+           "compute_capacity_rate_update", "coo_marginals"]
 
 
 def _code(dtype):
@@ -121,3 +121,25 @@ def compute_capacity_rate_update(loading_vi_shape, loading_vi_rate, prior_rate):
         _code(dt), n, nfactors, _p(_c(loading_vi_shape, dt)), _p(_c(loading_vi_rate, dt)),
         float(prior_rate), _p(out)))
     return out
+
+
+def coo_marginals(X):
+    """(row sums, column sums) of a COO matrix as float64 vectors: X.sum(1), X.sum(0) of
+    scHPF._get_empirical_hypers (scHPF_.py:847-879) in one threaded host pass."""
+    import ctypes
+    lib = _lib.load()
+    if not hasattr(X, "row"):
+        X = X.tocoo()
+    kinds = {np.dtype(np.int32): _lib.VAL_I32, np.dtype(np.int64): _lib.VAL_I64,
+             np.dtype(np.float32): _lib.VAL_F32, np.dtype(np.float64): _lib.VAL_F64}
+    data = np.ascontiguousarray(X.data)
+    if data.dtype not in kinds:
+        data = data.astype(np.float64)
+    row = np.ascontiguousarray(X.row, dtype=np.int32)
+    col = np.ascontiguousarray(X.col, dtype=np.int32)
+    rs = np.empty(X.shape[0], dtype=np.float64)
+    cs = np.empty(X.shape[1], dtype=np.float64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    _lib.check(lib.schpf_coo_marginals(data.shape[0], p(row), p(col), p(data), kinds[data.dtype],
+                                       X.shape[0], X.shape[1], p(rs), p(cs)))
+    return rs, cs

@@ -22,6 +22,7 @@ from scipy.sparse import coo_matrix
 from scipy.special import digamma, gammaln
 from sklearn.base import BaseEstimator
 
+from . import hpf_hip
 from . import loss as ls
 from ._version import __version__
 from .engine import DeviceCAVI
@@ -460,8 +461,15 @@ class scHPF(BaseEstimator):
         unset; dp is clipped to bp/1000 (scHPF_.py:847-879)."""
         bp, dp = self.bp, self.dp
 
+        marginals = []
+
         def mean_over_var(axis):
-            sums = X.sum(axis=axis)
+            # X.sum(axis) of the reference, both axes in one threaded pass of the library
+            # (schpf_coo_marginals): at 1e8 nonzeros SciPy's single-threaded sums were a sixth
+            # of a whole fit.  Counts are integers, so the sums -- and bp/dp -- are the same bits.
+            if not marginals:
+                marginals.extend(hpf_hip.coo_marginals(X))
+            sums = marginals[0] if axis == 1 else marginals[1]
             return np.mean(sums) / np.var(sums)
 
         if bp is None:

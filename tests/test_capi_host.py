@@ -120,9 +120,12 @@ def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_
 
 @pytest.mark.parametrize("lpc,wpb,win_rows,tasks", [(4, 8, 64, 64), (2, 4, 37, 1), (1, 1, 1000, 7), (8, 2, 5, 1000),
                                                   (16, 8, 300, 16)])
-def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks):
+@pytest.mark.parametrize("coo_order", ["shuffled", "row-major", "col-major"])
+def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, coo_order):
     X = synthetic_counts(257, 1031, 0.04, seed=5)
-    perm = np.random.RandomState(0).permutation(X.nnz)
+    # the plan builder has fast paths for input already sorted by (row, col) / (col, row)
+    perm = {"shuffled": np.random.RandomState(0).permutation(X.nnz),
+            "row-major": np.lexsort((X.col, X.row)), "col-major": np.lexsort((X.row, X.col))}[coo_order]
     row, col, val = X.row[perm], X.col[perm], X.data[perm].astype(np.float32)
     for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
         om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, tasks)

@@ -196,3 +196,26 @@ def test_trial_drivers_exported():
                  "loss_smoothing"):
         assert name in sig.parameters
     assert "njobs" in inspect.signature(run_trials_pool).parameters
+
+
+def test_coo_marginals_match_scipy_sums_exactly():
+    """schpf_coo_marginals (threaded, in the library) feeds the empirical bp/dp instead of
+    X.sum(1) / X.sum(0) (scHPF_.py:855-857): same integers, hence the same bp and dp bits."""
+    from schpf_amd import hpf_hip
+    X = golden_coo(load_golden("pbmc_like_data.npz"))
+    rs, cs = hpf_hip.coo_marginals(X)
+    assert np.array_equal(rs, np.asarray(X.sum(1)).ravel())
+    assert np.array_equal(cs, np.asarray(X.sum(0)).ravel())
+    for dt in (np.int64, np.float32, np.float64):
+        rs2, cs2 = hpf_hip.coo_marginals(X.astype(dt))
+        assert np.array_equal(rs, rs2) and np.array_equal(cs, cs2)
+    m = scHPF(5)
+    bp, dp = m._get_empirical_hypers(X)
+    want_bp = m.ap * np.mean(X.sum(1)) / np.var(X.sum(1))
+    want_dp = m.cp * np.mean(X.sum(0)) / np.var(X.sum(0))
+    assert bp == want_bp and dp == want_dp
+    bad = X.copy()
+    bad.row = bad.row.copy()
+    bad.row[3] = X.shape[0] + 5
+    with pytest.raises(ValueError):
+        hpf_hip.coo_marginals(bad)
