@@ -92,7 +92,7 @@ struct DevBuf {
     template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
 };
 
-template <typename U> void upload(DevBuf &b, const std::vector<U> &v, hipStream_t st)
+template <typename U, typename A> void upload(DevBuf &b, const std::vector<U, A> &v, hipStream_t st)
 {
     b.alloc(v.size() * sizeof(U));
     if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice, st));
@@ -288,7 +288,7 @@ template <typename T> struct Engine final : schpf_ctx {
         upload(pd.cptr, h.cptr, stream);
         pd.partials.alloc((size_t)std::max<int64_t>(h.n_chunks, 1) * KP * sizeof(T), true, stream);
         HIPCHK(hipStreamSynchronize(stream));
-        std::vector<uint32_t>().swap(h.entries);
+        schpf::BigVec<uint32_t>().swap(h.entries);
         std::vector<int32_t>().swap(h.chunk_major);
         std::vector<int32_t>().swap(h.chunk_natid);
         std::vector<int32_t>().swap(h.wave_slice);
@@ -322,7 +322,7 @@ template <typename T> struct Engine final : schpf_ctx {
         if (env_int("SCHPF_VERBOSE", 0))
             fprintf(stderr, "[schpf_hip]   tile plan %d x %d: host build %.3f s, H2D %.3f s (%.2f GB entries)\n",
                     h.n_major, h.n_minor, host_seconds, now_s() - t1, h.entries.size() * 4e-9);
-        std::vector<uint32_t>().swap(h.entries);
+        schpf::BigVec<uint32_t>().swap(h.entries);
         std::vector<uint16_t>().swap(h.steps);
         std::vector<int64_t>().swap(h.task_wave_off);
     }
@@ -411,7 +411,7 @@ template <typename T> struct Engine final : schpf_ctx {
         const bool verbose = env_int("SCHPF_VERBOSE", 0) != 0;
         const double t_start = now_s();
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
-        std::vector<float> v((size_t)nnz_);
+        schpf::BigVec<float> v((size_t)nnz_);   // no serial zero-fill: written by the threaded pass below
         {   // validate + convert, in parallel slabs (first offending entry per slab is reported)
             const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(schpf::host_threads(), nnz_ / 65536 + 1));
             std::vector<int64_t> bad_val((size_t)nth, -1), bad_idx((size_t)nth, -1);
@@ -901,7 +901,7 @@ template <typename T>
 void shape_update(int64_t nnz, int K, const void *xphi, const int32_t *keep, int nkeep, double prior, void *out)
 {
     check_indices(nnz, keep, nkeep, "keep");
-    std::vector<int32_t> order;
+    schpf::BigVec<int32_t> order;
     std::vector<int64_t> ptr;
     schpf::counting_sort_positions(nnz, keep, nkeep, order, ptr);
     TempStream ts;

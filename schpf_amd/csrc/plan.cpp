@@ -40,7 +40,7 @@ template <typename F> static void parallel_for(int64_t n, int nth, F f)
 // stable parallel counting sort of the sequence seq[0..n) (or 0..n-1 when seq == nullptr) by
 // key[seq[j]]: out[rank] = seq[j]; ptr = run pointers per key
 static void counting_sort_seq(int64_t n, const int32_t *seq, const int32_t *key, int nkeys,
-                              std::vector<int32_t> &out, std::vector<int64_t> &ptr)
+                              BigVec<int32_t> &out, std::vector<int64_t> &ptr)
 {
     int nth = host_threads();
     while (nth > 1 && (int64_t)nth * nkeys > (int64_t)48 << 20) nth /= 2;   // bound the counter table
@@ -71,14 +71,14 @@ static void counting_sort_seq(int64_t n, const int32_t *seq, const int32_t *key,
     });
 }
 
-void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vector<int32_t> &order,
+void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, BigVec<int32_t> &order,
                              std::vector<int64_t> &ptr)
 {
     counting_sort_seq(n, nullptr, key, nkeys, order, ptr);
 }
 
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
-                         std::vector<int32_t> &order, std::vector<int64_t> &mptr)
+                         BigVec<int32_t> &order, std::vector<int64_t> &mptr)
 {
     // What order did the caller's COO come in?  SciPy's canonical format (sum_duplicates, tocoo of
     // a CSR) is sorted by (row, col): the cell-side plan then needs no sort at all and the
@@ -117,7 +117,7 @@ void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor
         return;
     }
     // general case: minor first, then stable by major
-    std::vector<int32_t> by_minor;
+    BigVec<int32_t> by_minor;
     std::vector<int64_t> tmp_ptr;
     counting_sort_seq(nnz, nullptr, minor, n_minor, by_minor, tmp_ptr);
     counting_sort_seq(nnz, by_minor.data(), major, n_major, order, mptr);
@@ -158,7 +158,7 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
     P.n_windows = n_windows;
     P.nnz = nnz;
 
-    std::vector<int32_t> order;
+    BigVec<int32_t> order;
     std::vector<int64_t> mptr;
     sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
 
@@ -341,7 +341,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     const bool verbose = getenv("SCHPF_VERBOSE") && atoi(getenv("SCHPF_VERBOSE"));
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    std::vector<int32_t> order;
+    BigVec<int32_t> order;
     std::vector<int64_t> mptr;
     sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
     const double t1 = now();
@@ -385,8 +385,8 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
 
     // sorted copies: every later pass walks the rows' runs sequentially
     const int nth = host_threads();
-    std::vector<int32_t> s_minor((size_t)nnz);
-    std::vector<float> s_val((size_t)nnz);
+    BigVec<int32_t> s_minor((size_t)nnz);   // not zero-filled: written by the parallel pass below
+    BigVec<float> s_val((size_t)nnz);
     parallel_for(nnz, nth, [&](int64_t b, int64_t e, int) {
         for (int64_t j = b; j < e; ++j) {
             const int32_t pos = order[(size_t)j];

@@ -23,9 +23,46 @@
 // them in a fixed order: no atomics, run-to-run deterministic.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <sys/mman.h>
+#include <memory>
+#include <new>
+#include <utility>
 #include <vector>
 
 namespace schpf {
+
+// std::vector whose resize() does NOT zero-fill: the big per-nonzero arrays of a plan (hundreds of
+// MB) are written exactly once by parallel passes; a value-initialising resize would first-touch
+// every page from ONE thread, which at 1e8 nonzeros cost more than the passes themselves.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+    // large blocks: 2 MiB-aligned and advised as huge pages (first touch of 0.5 GB is then a few
+    // hundred page faults instead of 125 000)
+    T *allocate(std::size_t n)
+    {
+        const std::size_t bytes = n * sizeof(T);
+        if (bytes < ((std::size_t)4 << 20)) return static_cast<T *>(::operator new(bytes));
+        void *p = nullptr;
+        if (posix_memalign(&p, (std::size_t)2 << 20, bytes) != 0) throw std::bad_alloc();
+        madvise(p, bytes, MADV_HUGEPAGE);
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, std::size_t n) noexcept
+    {
+        if (n * sizeof(T) < ((std::size_t)4 << 20)) ::operator delete(p);
+        else free(p);
+    }
+};
+template <class T> using BigVec = std::vector<T, NoInitAlloc<T>>;
+
 
 struct SweepPlanHost {
     int n_major = 0, n_minor = 0;
@@ -37,14 +74,14 @@ struct SweepPlanHost {
     int64_t n_chunks = 0;   // natural chunks (rows of the partials matrix)
     int64_t n_slices = 0;
     int64_t n_waves = 0;    // launch size in wavefronts (multiple of 4)
-    std::vector<uint32_t> entries;        // 4 words per (step, chunk-slot): see above
+    BigVec<uint32_t> entries;             // 4 words per (step, chunk-slot): see above
     std::vector<int64_t> slice_off;       // [n_slices] offset into entries, in uint4 units
     std::vector<int32_t> slice_steps;     // [n_slices] number of uint4 steps
     std::vector<int32_t> chunk_major;     // [n_slices * cpw], -1 for an empty slot
     std::vector<int32_t> chunk_natid;     // [n_slices * cpw]
     std::vector<int32_t> wave_slice;      // [n_waves] slice id or -1 (XCD-aware order)
     std::vector<int32_t> cptr;            // [n_major + 1] natural-chunk ranges per major
-    std::vector<int32_t> order;           // [nnz] sorted position -> position in the caller's COO
+    BigVec<int32_t> order;                // [nnz] sorted position -> position in the caller's COO
     std::vector<int64_t> mptr;            // [n_major + 1] sorted-position ranges per major
 };
 
@@ -83,7 +120,7 @@ struct TilePlanHost {
     int win_rows = 0, n_windows = 0, windows_per_task = 0;
     int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
     bool packed = false;                  // 8-byte entries {idx0|idx1<<16, cnt0|cnt1<<16} instead of 16-byte
-    std::vector<uint32_t> entries;
+    BigVec<uint32_t> entries;
     std::vector<uint16_t> steps;
     std::vector<int32_t> block_rows;      // [n_blocks * gpb] major id or -1
     std::vector<int32_t> task_block, task_w0, task_w1;
@@ -91,7 +128,7 @@ struct TilePlanHost {
     std::vector<int64_t> task_work;    // [task] wave-steps the task's workgroup sits through (barrier-limited)
     std::vector<int32_t> task_order;   // tasks by decreasing work (launch order of the merged cell+gene launch)
     std::vector<int32_t> pfirst, pcount;  // [n_major]
-    std::vector<int32_t> order;           // [nnz] (major, minor)-sorted position -> caller's COO position
+    BigVec<int32_t> order;                // [nnz] (major, minor)-sorted position -> caller's COO position
     std::vector<int64_t> mptr;            // [n_major + 1]
 };
 
@@ -103,14 +140,14 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
 
 // positions sorted by (major, minor) and the per-major run pointers
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
-                         std::vector<int32_t> &order, std::vector<int64_t> &mptr);
+                         BigVec<int32_t> &order, std::vector<int64_t> &mptr);
 
 // number of host threads used by the builders ($SCHPF_HOST_THREADS, default min(cores, 32))
 int host_threads();
 
 // Stable counting sort of positions by key: order[j] = original position of the j-th
 // smallest key; ptr[k]..ptr[k+1] is the run of key k.
-void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, std::vector<int32_t> &order,
+void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, BigVec<int32_t> &order,
                              std::vector<int64_t> &ptr);
 
 }  // namespace schpf
