@@ -327,10 +327,12 @@ template <typename T> struct Engine final : schpf_ctx {
         std::vector<int64_t>().swap(h.task_wave_off);
     }
 
-    // Workgroup shape of the tile sweep.  Big problems: one 1024-thread workgroup per CU with a
-    // 152 KiB window (fewest stagings, longest row segments => least sliced-ELL padding).  When
-    // that leaves the 256 CUs short of tasks the workgroup is halved (64 KiB windows, two
-    // workgroups per CU) until there are enough (block, window) pairs.
+    // Workgroup shape of the tile sweep.  One 1024-thread workgroup per CU with a 152 KiB window
+    // (fewest stagings, longest row segments => least sliced-ELL padding) unless that leaves fewer
+    // than 64 (block, window) pairs per orientation; then the workgroup is halved (64 KiB windows,
+    // two workgroups per CU) until there are.  Measured on a 1/8 shard of C3 and on C2
+    // (SCHPF_MIN_PAIRS = 768 / 256 / 128 / 64): the large workgroup wins well below one task per
+    // CU, because both orientations share a launch and small windows cost padding and partials.
     void tile_shape(int n_major, int n_minor, int &wpb, int &win_rows, int &tasks) const
     {
         wpb = env_int("SCHPF_WPB", 0);
@@ -343,7 +345,7 @@ template <typename T> struct Engine final : schpf_ctx {
                 const int64_t wr = std::max<int64_t>(1, (int64_t)kb * 1024 / (int64_t)row_bytes);
                 const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
                 const int64_t windows = ((int64_t)n_minor + wr - 1) / wr;
-                if (blocks * windows >= 768 || wpb <= 2) break;
+                if (blocks * windows >= env_int("SCHPF_MIN_PAIRS", 64) || wpb <= 2) break;
                 wpb /= 2;
             }
         }
