@@ -263,6 +263,30 @@ def test_mass_conservation_at_benchmark_shape(amd, oracle):
         assert np.all(np.isfinite(ths)) and np.all(thr > 0) and np.all(ber > 0)
 
 
+def test_mass_conservation_at_headline_shape(amd, oracle, plan_kind):
+    """The same size-independent properties at the headline shape (BASELINE C3: 100k x 20k, K=20,
+    1024-thread workgroups, 152 KiB windows, the dual launch) with 1 % of the entries filled, in
+    float64: row / column sums, agreeing k-marginals, the loss against the oracle."""
+    if plan_kind != "tile":
+        pytest.skip("one plan kind is enough at this size")
+    X = synthetic_counts(100000, 20000, 0.01, seed=42)
+    K, a, c = 20, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=0)
+    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+        assert eng.plan_info()["chunk_len"] == -972          # 152 KiB / (20 x 8 B) rows per window
+        for _ in range(2):
+            eng.step()
+        ths, thr = eng.get_gamma("theta")
+        bes, ber = eng.get_gamma("beta")
+        loss = eng.mean_negative_pois_llh()
+    rows = np.asarray(X.sum(1)).ravel(); cols = np.asarray(X.sum(0)).ravel()
+    assert_allclose((ths - a).sum(1), rows, rtol=1e-11, atol=1e-11)
+    assert_allclose((bes - c).sum(1), cols, rtol=1e-11, atol=1e-10)
+    assert_allclose((ths - a).sum(0), (bes - c).sum(0), rtol=1e-10)
+    want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, ths, thr, bes, ber, nthreads=8)
+    assert_allclose(loss, want, rtol=1e-11)
+
+
 def test_engine_argument_errors(amd):
     X = synthetic_counts(50, 60, 0.1)
     with pytest.raises(ValueError):
