@@ -380,11 +380,18 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__device__ __forceinline__ double exp1_draw(uint64_t seed, uint64_t cell, uint64_t gene, unsigned k)
+// one 64-bit mix per nonzero (base), then a 32-bit finaliser per factor and a hardware log: the
+// start only has to be a valid random point of the simplex, not a high-grade variate
+__device__ __forceinline__ uint64_t draw_base(uint64_t seed, uint64_t cell, uint64_t gene)
 {
-    const uint64_t h = mix64(seed ^ mix64(cell * 0x100000001B3ull + gene) ^ ((uint64_t)k << 48));
-    const double u = ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0);  // (0,1)
-    return -log(u);
+    return mix64(seed ^ mix64(cell * 0x100000001B3ull + gene));
+}
+__device__ __forceinline__ double exp1_draw(uint64_t base, unsigned k)
+{
+    uint32_t z = (uint32_t)base ^ ((uint32_t)(base >> 32) + k * 0x9E3779B9u);
+    z ^= z >> 16; z *= 0x85EBCA6Bu; z ^= z >> 13; z *= 0xC2B2AE35u; z ^= z >> 16;   // murmur3 fmix32
+    const float u = ((float)(z >> 8) + 0.5f) * (1.0f / 16777216.0f);                 // (0,1)
+    return (double)(-__logf(u));
 }
 template <typename T, int NV, int LPC>
 __global__ __launch_bounds__(256) void random_phi_sweep_kernel(SweepArgs<T> a, uint64_t seed, int major_is_cell)
@@ -414,12 +421,13 @@ __global__ __launch_bounds__(256) void random_phi_sweep_kernel(SweepArgs<T> a, u
             if (!(x > 0.0)) continue;
             const uint64_t cell = major_is_cell ? (uint64_t)major : (uint64_t)minor;
             const uint64_t gene = major_is_cell ? (uint64_t)minor : (uint64_t)major;
+            const uint64_t base = draw_base(seed, cell, gene);
             double d[KL];
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < KL; ++k) {
                 const int f = factor_of<T, LPC>(k, sub);
-                d[k] = f < a.K ? exp1_draw(seed, cell, gene, (unsigned)f) : 0.0;
+                d[k] = f < a.K ? exp1_draw(base, (unsigned)f) : 0.0;
                 s += d[k];
             }
             s = group_sum<double, LPC>(s);
@@ -618,12 +626,13 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                             if (!(x > 0.0)) continue;
                             const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
                             const uint64_t gene = a.major_is_cell ? (uint64_t)minor : (uint64_t)major;
+                            const uint64_t base = draw_base(a.seed, cell, gene);
                             double d[KL];
                             double s = 0.0;
 #pragma unroll
                             for (int k = 0; k < KL; ++k) {
                                 const int f = factor_of<T, LPC>(k, sub);
-                                d[k] = f < a.K ? exp1_draw(a.seed, cell, gene, (unsigned)f) : 0.0;
+                                d[k] = f < a.K ? exp1_draw(base, (unsigned)f) : 0.0;
                                 s += d[k];
                             }
                             s = group_sum<double, LPC>(s);
