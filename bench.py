@@ -82,16 +82,24 @@ def convergence_run(N, G, K, dtype, density):
     host COO in, fitted model out: upload + plan build + iterations + loss checks + download."""
     from schpf import scHPF
     X = planted_block(N, G, K, target_events=int(N * G * density * 1.6), seed=42)
-    np.random.seed(0)
-    model = scHPF(K, dtype=dtype, verbose=False)
-    t0 = time.perf_counter()
-    model.fit(X, init="device")
-    wall = time.perf_counter() - t0
-    checks = len(model.loss)
+    # the number of iterations the stop rule takes depends on the random start: three seeds, each a
+    # complete fit from the host matrix; the headline is the median wall-clock
+    runs = []
+    for seed in (0, 1, 2):
+        np.random.seed(seed)
+        model = scHPF(K, dtype=dtype, verbose=False)
+        t0 = time.perf_counter()
+        model.fit(X, init="device")
+        wall = time.perf_counter() - t0
+        checks = len(model.loss)
+        runs.append({"seed": seed, "fit_wall_s": wall, "loss_checks": checks,
+                     "iterations": (checks - 1) * model.check_freq + 1,
+                     "first_loss": float(model.loss[0]), "final_loss": float(model.loss[-1])})
+    med = sorted(runs, key=lambda r: r["fit_wall_s"])[1]
     return {"data": "planted Gamma-Poisson, %d x %d, nnz %d (density %.4f), max count %d"
                     % (N, G, X.nnz, X.nnz / float(N) / G, int(X.data.max())),
-            "fit_wall_s": wall, "loss_checks": checks, "iterations": (checks - 1) * model.check_freq + 1,
-            "first_loss": float(model.loss[0]), "final_loss": float(model.loss[-1])}
+            "fit_wall_s": med["fit_wall_s"], "loss_checks": med["loss_checks"], "iterations": med["iterations"],
+            "first_loss": med["first_loss"], "final_loss": med["final_loss"], "runs": runs}
 
 
 def algorithmic_bytes(nnz, N, G, K, itemsize):
