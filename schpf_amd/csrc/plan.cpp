@@ -295,27 +295,42 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 // wished class if the segment still has such a nonzero, else from the fullest class.
 // seq[t] = index (within the segment) of the nonzero placed at position t.
 static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_slots, int lpc, int rank,
-                       std::vector<int32_t> &seq, std::vector<std::vector<int32_t>> &buckets)
+                       std::vector<int32_t> &seq, std::vector<int32_t> &scratch)
 {
-    const int n_classes = std::max(1, 16 / std::max(1, lpc));
+    const int n_classes = std::max(1, 16 / std::max(1, lpc));   // a power of two (lpc is)
     if (n_classes == 1 || n <= 2) {
         for (int t = 0; t < n; ++t) seq[(size_t)t] = t;
         return;
     }
-    for (int c = 0; c < n_classes; ++c) buckets[(size_t)c].clear();
-    for (int i = n - 1; i >= 0; --i) {   // reversed so that pop_back() hands them out in minor order
-        const int cls = (int)(((int64_t)(seg_minor[i] - base) * row_slots) % 16) / lpc;
-        buckets[(size_t)(cls % n_classes)].push_back(i);
+    // stable counting sort of the segment's positions by class; every class is then handed out
+    // front to back, i.e. in minor order
+    int lpc_shift = 0;
+    while ((1 << lpc_shift) < lpc) ++lpc_shift;
+    const unsigned cmask = (unsigned)n_classes - 1u;
+    int cnt[16] = {0}, head[16];
+    scratch.resize((size_t)n * 2);
+    int32_t *cls = scratch.data(), *pos = scratch.data() + n;
+    for (int i = 0; i < n; ++i) {
+        const unsigned c = ((((unsigned)(seg_minor[i] - base) * (unsigned)row_slots) & 15u) >> lpc_shift) & cmask;
+        cls[i] = (int32_t)c;
+        cnt[c]++;
+    }
+    int run = 0;
+    for (int c = 0; c < n_classes; ++c) { head[c] = run; run += cnt[c]; }
+    {
+        int cur[16];
+        for (int c = 0; c < n_classes; ++c) cur[c] = head[c];
+        for (int i = 0; i < n; ++i) pos[cur[cls[i]]++] = i;
     }
     for (int t = 0; t < n; ++t) {
-        int c = (rank + t) % n_classes;
-        if (buckets[(size_t)c].empty()) {
-            size_t best = 0;
+        int c = (int)(((unsigned)rank + (unsigned)t) & cmask);
+        if (cnt[c] == 0) {
+            int best = 0;
             for (int k = 0; k < n_classes; ++k)
-                if (buckets[(size_t)k].size() > best) { best = buckets[(size_t)k].size(); c = k; }
+                if (cnt[k] > best) { best = cnt[k]; c = k; }
         }
-        seq[(size_t)t] = buckets[(size_t)c].back();
-        buckets[(size_t)c].pop_back();
+        seq[(size_t)t] = pos[head[c]++];
+        cnt[c]--;
     }
 }
 
@@ -409,8 +424,9 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                 const int64_t end = mptr[(size_t)row + 1];
                 while (j < end) {           // runs of equal window (the row is sorted by minor)
                     const int32_t w = s_minor[(size_t)j] / win_rows;
+                    const int64_t bound = ((int64_t)w + 1) * win_rows;   // one division per run, not per nonzero
                     int64_t s = j;
-                    while (j < end && s_minor[(size_t)j] / win_rows == w) ++j;
+                    while (j < end && s_minor[(size_t)j] < bound) ++j;
                     const int64_t steps = (j - s + 1) / 2;   // two nonzeros per step
                     if (steps > 65535) { err[(size_t)t] = 1; continue; }
                     if (steps > st[w]) st[w] = (uint16_t)steps;
@@ -490,7 +506,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
         std::vector<int64_t> win_off((size_t)W);
         std::vector<int32_t> seq;
-        std::vector<std::vector<int32_t>> buckets(16);
+        std::vector<int32_t> buckets;   // scratch of bank_order
         for (int64_t b = b0; b < b1; ++b) {
             for (int v = 0; v < wpb; ++v) {
                 const size_t bw = (size_t)b * wpb + v;
@@ -514,8 +530,9 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                 const int64_t end = mptr[(size_t)row + 1];
                 while (j < end) {
                     const int32_t w = s_minor[(size_t)j] / win_rows;
+                    const int64_t bound = ((int64_t)w + 1) * win_rows;
                     int64_t s = j;
-                    while (j < end && s_minor[(size_t)j] / win_rows == w) ++j;
+                    while (j < end && s_minor[(size_t)j] < bound) ++j;
                     const int n = (int)(j - s);
                     seq.resize((size_t)n);
                     bank_order(s_minor.data() + s, n, w * win_rows, row_slots, lpc, pass_rank[(size_t)slot], seq, buckets);
