@@ -334,9 +334,12 @@ static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_sl
     }
 }
 
-void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
-                     int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, bool allow_packed, int row_slots, TilePlanHost &P)
+// ---- pieces of the tile plan that do not touch the nonzeros; shared by the host builder below
+// ---- and the device builder (plan_device.hip)
+
+// dimensions, rows by length -> blocks, tasks, partial-row bookkeeping; P.steps zeroed
+void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, int lpc, int waves_per_block,
+                     int win_rows, int target_tasks, const int64_t *mptr)
 {
     if (lpc < 1 || lpc > 64 || (64 % lpc) != 0) throw std::invalid_argument("lpc must divide 64");
     if (waves_per_block < 1 || waves_per_block > 16) throw std::invalid_argument("waves_per_block in [1,16]");
@@ -351,15 +354,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     P.win_rows = win_rows;
     P.n_windows = (n_minor + win_rows - 1) / win_rows;
     P.nnz = nnz;
-    const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb;
-
-    const bool verbose = getenv("SCHPF_VERBOSE") && atoi(getenv("SCHPF_VERBOSE"));
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    BigVec<int32_t> order;
-    std::vector<int64_t> mptr;
-    sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
-    const double t1 = now();
+    const int W = P.n_windows, gpb = P.gpb;
 
     // rows by length, longest first (stable): a wave's groups then carry similar loads
     std::vector<int32_t> rows((size_t)n_major);
@@ -397,6 +392,112 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
             const int32_t row = P.block_rows[(size_t)b * gpb + g];
             if (row >= 0) P.pfirst[(size_t)row] = (int32_t)(b * gpb + g);
         }
+    P.steps.assign((size_t)P.n_blocks * P.wpb * W, 0);
+}
+
+// with P.steps known: task work / merged-launch order, where every (block, wave)'s entries start
+// (wave_off, in step slots) and where each task's waves start; returns the number of step slots
+// including the zero padding the kernel's entry prefetch may read
+int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
+{
+    const int W = P.n_windows, wpb = P.wpb, gpw = P.gpw;
+    const int64_t wpt = P.windows_per_task;
+    const int nth = host_threads();
+    // work of a task: its workgroup runs, window by window, as long as its slowest wave (+ a
+    // staging of the window); task_order (longest first) feeds the merged cell+gene launch
+    P.task_work.assign((size_t)P.n_tasks, 0);
+    parallel_for(P.n_tasks, nth, [&](int64_t t0_, int64_t t1_, int) {
+        for (int64_t t = t0_; t < t1_; ++t) {
+            const int64_t b = P.task_block[(size_t)t];
+            int64_t work = 0;
+            for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
+                int mx = 0;
+                for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, P.steps[((size_t)b * wpb + v) * W + w]);
+                work += mx + 2;
+            }
+            P.task_work[(size_t)t] = work;
+        }
+    });
+    P.task_order.resize((size_t)P.n_tasks);
+    std::iota(P.task_order.begin(), P.task_order.end(), 0);
+    std::stable_sort(P.task_order.begin(), P.task_order.end(), [&](int32_t x, int32_t y) {
+        return P.task_work[(size_t)x] > P.task_work[(size_t)y];
+    });
+
+    wave_off.assign((size_t)P.n_blocks * wpb + 1, 0);   // entries of (block, wave), window order
+    for (size_t bw = 0; bw < (size_t)P.n_blocks * wpb; ++bw) {
+        int64_t tot = 0;
+        for (int w = 0; w < W; ++w) tot += P.steps[bw * W + w];
+        wave_off[bw + 1] = wave_off[bw] + tot * gpw;
+    }
+    P.task_wave_off.resize((size_t)P.n_tasks * wpb);
+    parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
+        for (int64_t b = b0; b < b1; ++b)
+            for (int v = 0; v < wpb; ++v) {
+                const size_t bw = (size_t)b * wpb + v;
+                int64_t off = wave_off[bw];
+                for (int w = 0; w < W; ++w) {
+                    const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
+                    if (w % wpt == 0) P.task_wave_off[tv] = off;
+                    off += (int64_t)P.steps[bw * W + w] * gpw;
+                }
+            }
+    });
+    // + zero slots: the kernel's ring prefetch (depth 4, advanced in batches of 4) reads up to
+    // 2 * 4 - 1 steps past a wave's last entry; 12 steps of padding keep that inside the buffer
+    return wave_off.back() + (int64_t)12 * gpw;
+}
+
+// rank of every group of a wave inside its ds_read_b128 pass (16 lanes served per LDS cycle)
+std::vector<int> tile_pass_rank(int lpc, int gpw)
+{
+    std::vector<int> pass_rank((size_t)gpw, 0);
+    static const int pass_of_quad[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};  // lanes 4q..4q+3
+    int seen[4] = {0, 0, 0, 0};
+    for (int g2 = 0; g2 < gpw; ++g2) {
+        const int lane0 = g2 * lpc;
+        if (lpc > 16) { pass_rank[(size_t)g2] = 0; continue; }
+        const int ps = pass_of_quad[lane0 / 4];
+        pass_rank[(size_t)g2] = seen[ps]++;
+    }
+    return pass_rank;
+}
+
+void tile_plan_report(const TilePlanHost &P)
+{
+    // where the stored slots go: nonzeros / sliced-ELL padding inside a wave / waiting at the
+    // window barrier for the slowest wave of the workgroup
+    const int W = P.n_windows, wpb = P.wpb, gpw = P.gpw;
+    int64_t wave_steps = 0, barrier_steps = 0;
+    for (int64_t b = 0; b < P.n_blocks; ++b)
+        for (int w = 0; w < W; ++w) {
+            int mx = 0;
+            for (int v = 0; v < wpb; ++v) {
+                const int s = P.steps.empty() ? 0 : P.steps[((size_t)b * wpb + v) * W + w];
+                wave_steps += s;
+                mx = std::max(mx, s);
+            }
+            barrier_steps += (int64_t)mx * wpb;
+        }
+    fprintf(stderr, "[schpf_hip]     nnz %lld, step slots x2 %lld (ELL fill %.3f), barrier-limited wave-steps %lld vs %lld "
+            "(%.3f)\n", (long long)P.nnz, (long long)(wave_steps * gpw * 2),
+            wave_steps ? (double)P.nnz / (double)(wave_steps * gpw * 2) : 0.0, (long long)barrier_steps,
+            (long long)wave_steps, wave_steps ? (double)wave_steps / (double)barrier_steps : 0.0);
+}
+
+void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
+                     int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
+                     int target_tasks, bool keep_order, bool allow_packed, int row_slots, TilePlanHost &P)
+{
+    const bool verbose = getenv("SCHPF_VERBOSE") && atoi(getenv("SCHPF_VERBOSE"));
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    BigVec<int32_t> order;
+    std::vector<int64_t> mptr;
+    sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
+    const double t1 = now();
+    tile_plan_begin(P, nnz, n_major, n_minor, lpc, waves_per_block, win_rows, target_tasks, mptr.data());
+    const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb;
 
     // sorted copies: every later pass walks the rows' runs sequentially
     const int nth = host_threads();
@@ -412,7 +513,6 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
 
     const double t2 = now();
     // per (block, wave, window): steps = ceil(longest segment / 2).  Threads own whole blocks.
-    P.steps.assign((size_t)P.n_blocks * wpb * W, 0);
     std::vector<int> err((size_t)nth + 1, 0);
     parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int t) {
         for (int64_t b = b0; b < b1; ++b)
@@ -436,37 +536,9 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     for (int e : err)
         if (e) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
 
-    // work of a task: its workgroup runs, window by window, as long as its slowest wave (+ a
-    // staging of the window).  task_order (longest first) is the order of the merged cell+gene
-    // launch; a single-plan launch keeps the natural order (neighbouring workgroups then stage
-    // the same windows, which measured ~3 % faster than longest-first)
-    P.task_work.assign((size_t)P.n_tasks, 0);
-    parallel_for(P.n_tasks, nth, [&](int64_t t0_, int64_t t1_, int) {
-        for (int64_t t = t0_; t < t1_; ++t) {
-            const int64_t b = P.task_block[(size_t)t];
-            int64_t work = 0;
-            for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
-                int mx = 0;
-                for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, P.steps[((size_t)b * wpb + v) * W + w]);
-                work += mx + 2;
-            }
-            P.task_work[(size_t)t] = work;
-        }
-    });
-    P.task_order.resize((size_t)P.n_tasks);
-    std::iota(P.task_order.begin(), P.task_order.end(), 0);
-    std::stable_sort(P.task_order.begin(), P.task_order.end(), [&](int32_t x, int32_t y) {
-        return P.task_work[(size_t)x] > P.task_work[(size_t)y];
-    });
-
     const double t3 = now();
-    std::vector<int64_t> wave_off((size_t)P.n_blocks * wpb + 1, 0);   // entries of (block, wave), window order
-    for (size_t bw = 0; bw < (size_t)P.n_blocks * wpb; ++bw) {
-        int64_t tot = 0;
-        for (int w = 0; w < W; ++w) tot += P.steps[bw * W + w];
-        wave_off[bw + 1] = wave_off[bw] + tot * gpw;
-    }
-    const int64_t total = wave_off.back();
+    std::vector<int64_t> wave_off;
+    const int64_t total_padded = tile_plan_offsets(P, wave_off);
     // packed entries (8 bytes per step: two 16-bit window-local indices + two 16-bit counts) when
     // every count fits 16 bits -- UMI counts do; otherwise 16 bytes per step (32-bit index, float)
     bool packed = allow_packed && win_rows <= 65536;
@@ -482,41 +554,17 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     }
     P.packed = packed;
     const int epw = packed ? 2 : 4;      // 32-bit words per step slot
-    // + zero slots: the kernel's ring prefetch (depth 4, advanced in batches of 4) reads up to
-    // 2 * 4 - 1 steps past a wave's last entry; 12 steps of padding keep that inside the buffer
-    const int64_t total_padded = total + (int64_t)12 * gpw;
     P.entries.resize((size_t)total_padded * epw);
     parallel_for(total_padded * epw, nth, [&](int64_t b, int64_t e, int) {
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
-    P.task_wave_off.resize((size_t)P.n_tasks * wpb);
     // fill: walk each row's nonzeros in minor order; position inside its window segment = t
-    // rank of every group of a wave inside its ds_read_b128 pass (16 lanes served per LDS cycle)
-    std::vector<int> pass_rank((size_t)gpw, 0);
-    {
-        static const int pass_of_quad[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};  // lanes 4q..4q+3
-        int seen[4] = {0, 0, 0, 0};
-        for (int g2 = 0; g2 < gpw; ++g2) {
-            const int lane0 = g2 * lpc;
-            if (lpc > 16) { pass_rank[(size_t)g2] = 0; continue; }
-            const int ps = pass_of_quad[lane0 / 4];
-            pass_rank[(size_t)g2] = seen[ps]++;
-        }
-    }
+    const std::vector<int> pass_rank = tile_pass_rank(lpc, gpw);
     parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
         std::vector<int64_t> win_off((size_t)W);
         std::vector<int32_t> seq;
         std::vector<int32_t> buckets;   // scratch of bank_order
         for (int64_t b = b0; b < b1; ++b) {
-            for (int v = 0; v < wpb; ++v) {
-                const size_t bw = (size_t)b * wpb + v;
-                int64_t off = wave_off[bw];
-                for (int w = 0; w < W; ++w) {
-                    const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
-                    if (w % wpt == 0) P.task_wave_off[tv] = off;
-                    off += (int64_t)P.steps[bw * W + w] * gpw;
-                }
-            }
             for (int g = 0; g < gpb; ++g) {
                 const int32_t row = P.block_rows[(size_t)b * gpb + g];
                 if (row < 0) continue;
@@ -558,23 +606,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     if (verbose) {
         fprintf(stderr, "[schpf_hip]     sort %.3f s, sorted copies %.3f s, steps %.3f s, alloc+fill %.3f s\n", t1 - t0,
                 t2 - t1, t3 - t2, now() - t3);
-        // where the stored slots go: nonzeros / sliced-ELL padding inside a wave / waiting at the
-        // window barrier for the slowest wave of the workgroup
-        int64_t wave_steps = 0, barrier_steps = 0;
-        for (int64_t b = 0; b < P.n_blocks; ++b)
-            for (int w = 0; w < W; ++w) {
-                int mx = 0;
-                for (int v = 0; v < wpb; ++v) {
-                    const int s = P.steps.empty() ? 0 : P.steps[((size_t)b * wpb + v) * W + w];
-                    wave_steps += s;
-                    mx = std::max(mx, s);
-                }
-                barrier_steps += (int64_t)mx * wpb;
-            }
-        fprintf(stderr, "[schpf_hip]     nnz %lld, step slots x2 %lld (ELL fill %.3f), barrier-limited wave-steps %lld vs %lld "
-                "(%.3f)\n", (long long)nnz, (long long)(wave_steps * gpw * 2),
-                wave_steps ? (double)nnz / (double)(wave_steps * gpw * 2) : 0.0, (long long)barrier_steps,
-                (long long)wave_steps, wave_steps ? (double)wave_steps / (double)barrier_steps : 0.0);
+        tile_plan_report(P);
     }
     if (keep_order) {
         P.order.swap(order);
