@@ -113,6 +113,8 @@ struct PlanDev {
 struct TileDev {
     schpf::TilePlanHost host;   // entries/steps cleared after upload; order/mptr kept
     DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, pfirst, pcount, partials;
+    DevBuf order_dev;           // device-built plans: (major, minor)-sorted position -> caller's COO position
+    bool order_identity = false; //                    ... or the input was already in that order
     int64_t n_tasks = 0, entry_slots = 0, n_wave_out = 0;
     int threads = 512;
     size_t lds_bytes = 0;
@@ -301,15 +303,26 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         const double t1 = now_s();
         auto &h = td.host;
+        td.entry_slots = (int64_t)h.entries.size() / (h.packed ? 1 : 2);
+        upload(td.entries, h.entries, stream);
+        upload(td.steps, h.steps, stream);
+        finish_tile(td);
+        if (env_int("SCHPF_VERBOSE", 0))
+            fprintf(stderr, "[schpf_hip]   tile plan %d x %d: host build %.3f s, H2D %.3f s (%.2f GB entries)\n",
+                    h.n_major, h.n_minor, host_seconds, now_s() - t1, h.entries.size() * 4e-9);
+        schpf::BigVec<uint32_t>().swap(h.entries);
+    }
+
+    // the small arrays of a tile plan (its entries and steps are on the device already)
+    void finish_tile(TileDev &td)
+    {
+        auto &h = td.host;
         const int wpb = h.wpb;
         td.n_tasks = h.n_tasks;
         td.threads = 64 * wpb;
         td.lds_bytes = (size_t)h.win_rows * KP * sizeof(T);
-        td.entry_slots = (int64_t)h.entries.size() / (h.packed ? 1 : 2);
         td.packed = h.packed;
         td.n_wave_out = h.n_tasks * wpb;
-        upload(td.entries, h.entries, stream);
-        upload(td.steps, h.steps, stream);
         upload(td.block_rows, h.block_rows, stream);
         upload(td.task_block, h.task_block, stream);
         upload(td.task_w0, h.task_w0, stream);
@@ -319,12 +332,50 @@ template <typename T> struct Engine final : schpf_ctx {
         upload(td.pcount, h.pcount, stream);
         td.partials.alloc((size_t)std::max<int64_t>(h.n_partial_rows, 1) * KP * sizeof(T), true, stream);
         HIPCHK(hipStreamSynchronize(stream));
-        if (env_int("SCHPF_VERBOSE", 0))
-            fprintf(stderr, "[schpf_hip]   tile plan %d x %d: host build %.3f s, H2D %.3f s (%.2f GB entries)\n",
-                    h.n_major, h.n_minor, host_seconds, now_s() - t1, h.entries.size() * 4e-9);
-        schpf::BigVec<uint32_t>().swap(h.entries);
         std::vector<uint16_t>().swap(h.steps);
         std::vector<int64_t>().swap(h.task_wave_off);
+    }
+
+    // Both tile plans built by device passes over the uploaded COO (plan_device.hip): same plans,
+    // bit for bit, as build_tiles(); SCHPF_DEVICE_PLAN=0 selects the host builder.
+    void build_tiles_device(const int32_t *row, const int32_t *col, const float *val, bool packed_ok)
+    {
+        const double t0 = now_s();
+        int wpb_c, wr_c, tk_c, wpb_g, wr_g, tk_g;
+        tile_shape(N, G, wpb_c, wr_c, tk_c);
+        tile_shape(G, N, wpb_g, wr_g, tk_g);
+        const bool allow_pack = env_int("SCHPF_PACK", 1) != 0;
+        const int row_slots = env_int("SCHPF_BANK_ORDER", 1) ? (int)((size_t)KP * sizeof(T) / 16) : 0;
+        bool rc_sorted = true, cr_sorted = true;
+        schpf::coo_order_flags(nnz, row, col, rc_sorted, cr_sorted);
+        DevBuf d_row, d_col, d_val;
+        d_row.alloc((size_t)nnz * 4); d_col.alloc((size_t)nnz * 4); d_val.alloc((size_t)nnz * 4);
+        if (nnz > 0) {
+            HIPCHK(hipMemcpyAsync(d_row.p, row, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_col.p, col, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(d_val.p, val, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
+        }
+        const double t1 = now_s();
+        for (int side = 0; side < 2; ++side) {
+            TileDev &td = side == 0 ? tcell : tgene;
+            void *e = nullptr, *s = nullptr, *o = nullptr;
+            size_t eb = 0;
+            const bool presorted = side == 0 ? rc_sorted : cr_sorted;
+            schpf::build_tile_plan_device((void *)stream, nnz, side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>(),
+                                          side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>(), d_val.as<float>(),
+                                          presorted, packed_ok, side == 0 ? N : G, side == 0 ? G : N, LPC,
+                                          side == 0 ? wpb_c : wpb_g, side == 0 ? wr_c : wr_g, side == 0 ? tk_c : tk_g,
+                                          allow_pack, row_slots, td.host, &e, &eb, &s, &o);
+            td.entries.release(); td.entries.p = e; td.entries.bytes = eb;
+            td.steps.release(); td.steps.p = s; td.steps.bytes = td.host.steps.size() * 2;
+            td.order_dev.release(); td.order_dev.p = o; td.order_dev.bytes = o ? (size_t)nnz * 4 : 0;
+            td.order_identity = presorted;
+            td.entry_slots = (int64_t)(eb / 4) / (td.host.packed ? 1 : 2);
+            finish_tile(td);
+        }
+        if (env_int("SCHPF_VERBOSE", 0))
+            fprintf(stderr, "[schpf_hip]   tile plans on the device: H2D of the COO %.3f s, both plans %.3f s (%.2f GB entries)\n",
+                    t1 - t0, now_s() - t1, (tcell.entries.bytes + tgene.entries.bytes) * 1e-9);
     }
 
     // Workgroup shape of the tile sweep.  One 1024-thread workgroup per CU with a 152 KiB window
@@ -419,9 +470,11 @@ template <typename T> struct Engine final : schpf_ctx {
         const double t_start = now_s();
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
         schpf::BigVec<float> v((size_t)nnz_);   // no serial zero-fill: written by the threaded pass below
+        bool packed_ok = true;
         {   // validate + convert, in parallel slabs (first offending entry per slab is reported)
             const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(schpf::host_threads(), nnz_ / 65536 + 1));
             std::vector<int64_t> bad_val((size_t)nth, -1), bad_idx((size_t)nth, -1);
+            std::vector<char> wide((size_t)nth, 0);   // a count that does not fit the packed 16-bit entry format
             std::vector<std::thread> th;
             for (int t = 0; t < nth; ++t)
                 th.emplace_back([&, t] {
@@ -439,10 +492,12 @@ template <typename T> struct Engine final : schpf_ctx {
                         if ((row[i] < 0 || row[i] >= N || col[i] < 0 || col[i] >= G) && bad_idx[(size_t)t] < 0)
                             bad_idx[(size_t)t] = i;
                         v[(size_t)i] = f;
+                        if (!(f <= 65535.0f) || f != (float)(uint32_t)f) wide[(size_t)t] = 1;
                     }
                 });
             for (auto &x : th) x.join();
             if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
+            for (int t = 0; t < nth; ++t) packed_ok = packed_ok && !wide[(size_t)t];
             for (int t = 0; t < nth; ++t) {
                 if (bad_idx[(size_t)t] >= 0)
                     throw std::invalid_argument("COO index out of range at entry " + std::to_string(bad_idx[(size_t)t]));
@@ -468,7 +523,8 @@ template <typename T> struct Engine final : schpf_ctx {
         cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
         int64_t n_out;
         if (use_tile) {
-            build_tiles(row, col, v.data());
+            if (env_int("SCHPF_DEVICE_PLAN", 1)) build_tiles_device(row, col, v.data(), packed_ok);
+            else build_tiles(row, col, v.data());
             n_out = tcell.n_wave_out;
         } else {
             const int wc = pick_windows((size_t)G * KP * sizeof(T), "SCHPF_WINDOWS_CELL");
@@ -662,6 +718,23 @@ template <typename T> struct Engine final : schpf_ctx {
         if (!have_coo) throw std::logic_error("no count matrix uploaded (schpf_upload_coo)");
     }
 
+    // (major, minor)-sorted position -> position in the caller's COO, on the device
+    const int *order_of(int side, DevBuf &scratch)
+    {
+        if (!use_tile) { upload(scratch, side == 0 ? cell.host.order : gene.host.order, stream); return scratch.as<int>(); }
+        TileDev &td = side == 0 ? tcell : tgene;
+        if (td.order_dev.p) return td.order_dev.as<int>();
+        if (td.order_identity) {
+            std::vector<int32_t> iota((size_t)nnz);
+            for (int64_t j = 0; j < nnz; ++j) iota[(size_t)j] = (int32_t)j;
+            upload(scratch, iota, stream);
+            HIPCHK(hipStreamSynchronize(stream));   // iota dies with this scope
+            return scratch.as<int>();
+        }
+        upload(scratch, td.host.order, stream);
+        return scratch.as<int>();
+    }
+
     void init_phi_host(const double *xphi) override
     {
         need_coo();
@@ -669,14 +742,14 @@ template <typename T> struct Engine final : schpf_ctx {
         dx.alloc((size_t)nnz * K * sizeof(double));
         HIPCHK(hipMemcpyAsync(dx.p, xphi, (size_t)nnz * K * sizeof(double), hipMemcpyHostToDevice, stream));
         dense_cell.alloc((size_t)N * K * sizeof(T));
-        upload(ord, use_tile ? tcell.host.order : cell.host.order, stream);
+        const int *ord_c = order_of(0, ord);
         upload(mp, use_tile ? tcell.host.mptr : cell.host.mptr, stream);
-        HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord.as<int>(), mp.as<int64_t>(), N, K,
+        HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord_c, mp.as<int64_t>(), N, K,
                                             dense_cell.as<T>(), stream));
         HIPCHK(hipStreamSynchronize(stream));
-        upload(ord, use_tile ? tgene.host.order : gene.host.order, stream);
+        const int *ord_g = order_of(1, ord);
         upload(mp, use_tile ? tgene.host.mptr : gene.host.mptr, stream);
-        HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord.as<int>(), mp.as<int64_t>(), G, K,
+        HIPCHK(schpf::launch_segment_sum<T>(dx.as<double>(), ord_g, mp.as<int64_t>(), G, K,
                                             exchange_buf.as<T>(), stream));
         HIPCHK(hipStreamSynchronize(stream));
         pending_init = 1;

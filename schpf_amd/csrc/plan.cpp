@@ -77,12 +77,8 @@ void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, BigVec<in
     counting_sort_seq(n, nullptr, key, nkeys, order, ptr);
 }
 
-void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
-                         BigVec<int32_t> &order, std::vector<int64_t> &mptr)
+void coo_order_flags(int64_t nnz, const int32_t *major, const int32_t *minor, bool &sorted_mm, bool &sorted_nm)
 {
-    // What order did the caller's COO come in?  SciPy's canonical format (sum_duplicates, tocoo of
-    // a CSR) is sorted by (row, col): the cell-side plan then needs no sort at all and the
-    // gene-side plan one stable pass.  One parallel scan decides.
     const int nth = host_threads();
     std::vector<char> not_mm((size_t)nth + 1, 0), not_nm((size_t)nth + 1, 0);
     parallel_for(nnz, nth, [&](int64_t b, int64_t e, int t) {
@@ -95,8 +91,19 @@ void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor
         not_mm[(size_t)t] = bad_mm;
         not_nm[(size_t)t] = bad_nm;
     });
-    bool sorted_mm = true, sorted_nm = true;
+    sorted_mm = sorted_nm = true;
     for (int t = 0; t <= nth; ++t) { sorted_mm = sorted_mm && !not_mm[(size_t)t]; sorted_nm = sorted_nm && !not_nm[(size_t)t]; }
+}
+
+void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
+                         BigVec<int32_t> &order, std::vector<int64_t> &mptr)
+{
+    // What order did the caller's COO come in?  SciPy's canonical format (sum_duplicates, tocoo of
+    // a CSR) is sorted by (row, col): the cell-side plan then needs no sort at all and the
+    // gene-side plan one stable pass.  One parallel scan decides.
+    const int nth = host_threads();
+    bool sorted_mm = true, sorted_nm = true;
+    coo_order_flags(nnz, major, minor, sorted_mm, sorted_nm);
     if (sorted_mm) {
         // identity order; run pointers from the positions where the major index changes
         order.resize((size_t)nnz);

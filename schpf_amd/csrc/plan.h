@@ -157,4 +157,16 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off);
 std::vector<int> tile_pass_rank(int lpc, int gpw);
 void tile_plan_report(const TilePlanHost &P);
 
+// the (major, minor) / (minor, major) order of a host COO (one threaded scan)
+void coo_order_flags(int64_t nnz, const int32_t *major, const int32_t *minor, bool &sorted_major_minor,
+                     bool &sorted_minor_major);
+
+// plan_device.hip: the same plan built by device passes over an uploaded COO (hipStream_t is a
+// pointer type; declared as void * here so that host-only translation units need no HIP header)
+void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, const int32_t *d_minor,
+                            const float *d_val, bool presorted, bool packed_ok, int n_major, int n_minor, int lpc,
+                            int waves_per_block, int win_rows, int target_tasks, bool allow_packed, int row_slots,
+                            TilePlanHost &P, void **out_entries, size_t *out_entries_bytes, void **out_steps,
+                            void **out_order);
+
 }  // namespace schpf

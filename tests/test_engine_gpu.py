@@ -496,3 +496,35 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
     for other in results[1:]:
         for (s0, r0), (s1, r1) in zip(results[0], other):
             assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
+
+
+@pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
+@pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True)])
+def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_order, dtype, K, big):
+    """The plan built by device passes (plan_device.hip: radix sort, step counts, bank-ordered
+    fill) is the host builder's plan bit for bit: same entry order => same summation order => the
+    engines agree in every bit after three iterations, from a host-drawn t=0 included (that path
+    uses the plan's sort permutation)."""
+    if plan_kind != "tile":
+        pytest.skip("the gather plan is always built on the host")
+    from scipy.sparse import coo_matrix
+    X = synthetic_counts(2500, 1800, 0.05, seed=11)
+    data = X.data.copy()
+    if big:
+        data[::7] += 70000          # counts beyond 16 bits: unpacked 16-byte entries
+    perm = {"canonical": np.arange(X.nnz), "shuffled": np.random.RandomState(3).permutation(X.nnz),
+            "col-major": np.lexsort((X.row, X.col))}[coo_order]
+    Xp = coo_matrix((data[perm], (X.row[perm], X.col[perm])), shape=X.shape)
+    bp, dp, st = random_state(oracle, Xp, K, dtype, seed=4)
+    phi = np.random.RandomState(5).dirichlet(np.ones(K), Xp.nnz)
+    results = []
+    for device_plan in ("1", "0"):
+        monkeypatch.setenv("SCHPF_DEVICE_PLAN", device_plan)
+        with load_engine(amd, Xp, K, dtype, st, 0.3, 0.3, bp, dp) as eng:
+            eng.init_phi_host(Xp.data[:, None] * phi)
+            for _ in range(3):
+                eng.step()
+            results.append([eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")] + [eng.plan_info()])
+    assert results[0][4] == results[1][4]
+    for (s0, r0), (s1, r1) in zip(results[0][:4], results[1][:4]):
+        assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
