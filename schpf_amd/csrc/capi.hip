@@ -373,6 +373,7 @@ template <typename T> struct Engine final : schpf_ctx {
             td.entry_slots = (int64_t)(eb / 4) / (td.host.packed ? 1 : 2);
             finish_tile(td);
         }
+        build_dual_order();
         if (env_int("SCHPF_VERBOSE", 0))
             fprintf(stderr, "[schpf_hip]   tile plans on the device: H2D of the COO %.3f s, both plans %.3f s (%.2f GB entries)\n",
                     t1 - t0, now_s() - t1, (tcell.entries.bytes + tgene.entries.bytes) * 1e-9);
@@ -438,6 +439,11 @@ template <typename T> struct Engine final : schpf_ctx {
         if (err) std::rethrow_exception(err);
         upload_tile(tcell, secs_cell);
         upload_tile(tgene, secs_gene);
+        build_dual_order();
+    }
+
+    void build_dual_order()
+    {
         // Both sweeps of an iteration in one launch (kernels.h launch_tile_sweep_dual) when the two
         // plans agree on the workgroup shape: slots = all tasks of both plans, longest first
         dual_slots = 0;

@@ -72,29 +72,40 @@ struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
 };
 
-// per (block, wave, window): steps = ceil(longest segment / 2); one thread per row
+// first position in [lo, hi) whose minor index is >= key (the row's minors ascend)
+__device__ __forceinline__ int64_t lower_bound_minor(const int32_t *__restrict__ s_minor, int64_t lo, int64_t hi, int64_t key)
+{
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)s_minor[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// One thread per (row, window) segment -- NOT per row: real count matrices have rows (genes) with
+// 1e5 nonzeros next to rows with ten, and a thread per row would serialise on the longest.
+// per (block, wave, window): steps = ceil(longest segment / 2)
 __global__ void steps_kernel(Geometry g, int64_t n_slots, const int32_t *__restrict__ block_rows,
                              const int64_t *__restrict__ mptr, const int32_t *__restrict__ s_minor,
                              unsigned *__restrict__ steps32, int *__restrict__ err)
 {
-    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
+    const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (id >= n_slots * g.W) return;
+    const int64_t slot = id / g.W;
+    const int w = (int)(id % g.W);
     const int32_t row = block_rows[slot];
     if (row < 0) return;
+    const int64_t r0 = mptr[row], r1 = mptr[row + 1];
+    if (r0 == r1) return;
+    const int64_t lo = lower_bound_minor(s_minor, r0, r1, (int64_t)w * g.win_rows);
+    const int64_t hi = lower_bound_minor(s_minor, lo, r1, ((int64_t)w + 1) * g.win_rows);
+    if (hi == lo) return;
+    const int64_t steps = (hi - lo + 1) / 2;
+    if (steps > 65535) { *err = 1; return; }
     const int64_t b = slot / g.gpb;
     const int v = (int)(slot % g.gpb) / g.gpw;
-    unsigned *st = steps32 + ((size_t)b * g.wpb + v) * g.W;
-    int64_t j = mptr[row];
-    const int64_t end = mptr[row + 1];
-    while (j < end) {
-        const int32_t w = s_minor[j] / g.win_rows;
-        const int64_t bound = ((int64_t)w + 1) * g.win_rows;
-        const int64_t s = j;
-        while (j < end && s_minor[j] < bound) ++j;
-        const int64_t steps = (j - s + 1) / 2;
-        if (steps > 65535) { *err = 1; continue; }
-        atomicMax(st + w, (unsigned)steps);
-    }
+    atomicMax(steps32 + ((size_t)b * g.wpb + v) * g.W + w, (unsigned)steps);
 }
 
 __device__ __forceinline__ int bank_class(const Geometry &g, int32_t local)
@@ -102,73 +113,68 @@ __device__ __forceinline__ int bank_class(const Geometry &g, int32_t local)
     return (int)(((((unsigned)local * (unsigned)g.row_slots) & 15u) >> g.lpc_shift) & (unsigned)(g.n_classes - 1));
 }
 
-// fill: one thread per row; inside a window segment the nonzeros are dealt to the steps in the
+// fill, one thread per (row, window) segment: the segment's nonzeros are dealt to the steps in the
 // LDS-bank-aware order of plan.cpp::bank_order (wished class (rank + t) mod classes, else the
-// fullest class; inside a class in minor order)
+// fullest class; inside a class in minor order).  win_off[(block, wave), window] = first step
+// slot of that window's entries.
 __global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restrict__ block_rows,
                             const int64_t *__restrict__ mptr, const int32_t *__restrict__ s_minor,
-                            const float *__restrict__ s_val, const uint16_t *__restrict__ steps,
-                            const int64_t *__restrict__ wave_off, const int *__restrict__ pass_rank,
-                            uint32_t *__restrict__ entries)
+                            const float *__restrict__ s_val, const int64_t *__restrict__ win_off,
+                            const int *__restrict__ pass_rank, uint32_t *__restrict__ entries)
 {
-    const int64_t slot = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
+    const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (id >= n_slots * g.W) return;
+    const int64_t slot = id / g.W;
+    const int w = (int)(id % g.W);
     const int32_t row = block_rows[slot];
     if (row < 0) return;
+    const int64_t r0 = mptr[row], r1 = mptr[row + 1];
+    if (r0 == r1) return;
+    const int32_t base = w * g.win_rows;
+    const int64_t s = lower_bound_minor(s_minor, r0, r1, (int64_t)base);
+    const int64_t e_ = lower_bound_minor(s_minor, s, r1, (int64_t)base + g.win_rows);
+    const int n = (int)(e_ - s);
+    if (n == 0) return;
     const int64_t b = slot / g.gpb;
     const int gi = (int)(slot % g.gpb);
     const int gslot = gi % g.gpw;
     const size_t bw = (size_t)b * g.wpb + gi / g.gpw;
-    const uint16_t *st = steps + bw * g.W;
     const int rank = pass_rank[gslot];
-    int64_t win_off = wave_off[bw];
-    int wcur = 0;
-    int64_t j = mptr[row];
-    const int64_t end = mptr[row + 1];
-    while (j < end) {
-        const int32_t w = s_minor[j] / g.win_rows;
-        while (wcur < w) { win_off += (int64_t)st[wcur] * g.gpw; ++wcur; }
-        const int32_t base = w * g.win_rows;
-        const int64_t bound = (int64_t)base + g.win_rows;
-        const int64_t s = j;
-        int cnt[16];
-        int64_t cur[16];
-        for (int c = 0; c < 16; ++c) { cnt[c] = 0; cur[c] = s; }
-        while (j < end && s_minor[j] < bound) {
-            if (g.n_classes > 1) cnt[bank_class(g, s_minor[j] - base)]++;
-            ++j;
+    const int64_t off = win_off[bw * g.W + w];
+    const bool ordered = g.n_classes > 1 && n > 2;
+    int cnt[16];
+    int64_t cur[16];
+    for (int c = 0; c < 16; ++c) { cnt[c] = 0; cur[c] = s; }
+    if (ordered)
+        for (int64_t j = s; j < e_; ++j) cnt[bank_class(g, s_minor[j] - base)]++;
+    for (int t = 0; t < n; ++t) {
+        int64_t src;
+        if (!ordered) {
+            src = s + t;
+        } else {
+            int c = (int)(((unsigned)rank + (unsigned)t) & (unsigned)(g.n_classes - 1));
+            if (cnt[c] == 0) {
+                int best = 0;
+                for (int k = 0; k < g.n_classes; ++k)
+                    if (cnt[k] > best) { best = cnt[k]; c = k; }
+            }
+            int64_t q = cur[c];
+            while (bank_class(g, s_minor[q] - base) != c) ++q;   // next unused nonzero of class c, in minor order
+            src = q;
+            cur[c] = q + 1;
+            cnt[c]--;
         }
-        const int n = (int)(j - s);
-        const bool ordered = g.n_classes > 1 && n > 2;
-        for (int t = 0; t < n; ++t) {
-            int64_t src;
-            if (!ordered) {
-                src = s + t;
-            } else {
-                int c = (int)(((unsigned)rank + (unsigned)t) & (unsigned)(g.n_classes - 1));
-                if (cnt[c] == 0) {
-                    int best = 0;
-                    for (int k = 0; k < g.n_classes; ++k)
-                        if (cnt[k] > best) { best = cnt[k]; c = k; }
-                }
-                int64_t q = cur[c];
-                while (bank_class(g, s_minor[q] - base) != c) ++q;   // next unused nonzero of class c, in minor order
-                src = q;
-                cur[c] = q + 1;
-                cnt[c]--;
-            }
-            const int32_t mn = s_minor[src];
-            const size_t step_slot = (size_t)win_off + (size_t)(t >> 1) * g.gpw + gslot;
-            if (g.packed) {
-                uint32_t *e = entries + step_slot * 2;
-                const int sh = (t & 1) * 16;
-                e[0] |= (uint32_t)(mn - base) << sh;
-                e[1] |= (uint32_t)s_val[src] << sh;
-            } else {
-                uint32_t *e = entries + step_slot * 4 + (size_t)(t & 1) * 2;
-                e[0] = (uint32_t)(mn - base);
-                e[1] = __float_as_uint(s_val[src]);
-            }
+        const int32_t mn = s_minor[src];
+        const size_t step_slot = (size_t)off + (size_t)(t >> 1) * g.gpw + gslot;
+        if (g.packed) {
+            uint32_t *e = entries + step_slot * 2;
+            const int sh = (t & 1) * 16;
+            e[0] |= (uint32_t)(mn - base) << sh;
+            e[1] |= (uint32_t)s_val[src] << sh;
+        } else {
+            uint32_t *e = entries + step_slot * 4 + (size_t)(t & 1) * 2;
+            e[0] = (uint32_t)(mn - base);
+            e[1] = __float_as_uint(s_val[src]);
         }
     }
 }
@@ -249,8 +255,9 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         Tmp d_steps32(n_steps * 4 + 4);
         PD_CHECK(hipMemsetAsync(d_steps32.p, 0, n_steps * 4 + 4, st));
         int *d_err = d_steps32.as<int>() + n_steps;
-        if (n_slots > 0)
-            hipLaunchKernelGGL(steps_kernel, dim3(grid_for(n_slots, 64)), dim3(64), 0, st, g, n_slots,
+        const int64_t n_segments = n_slots * P.n_windows;
+        if (n_segments > 0)
+            hipLaunchKernelGGL(steps_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
                                d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, d_steps32.as<unsigned>(), d_err);
         std::vector<uint32_t> steps32(n_steps + 1);
         PD_CHECK(hipMemcpyAsync(steps32.data(), d_steps32.p, (n_steps + 1) * 4, hipMemcpyDeviceToHost, st));
@@ -276,14 +283,22 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         *out_steps = d_steps16;
         PD_CHECK(hipMemsetAsync(d_entries, 0, entries_bytes, st));
         PD_CHECK(hipMemcpyAsync(d_steps16, P.steps.data(), n_steps * 2, hipMemcpyHostToDevice, st));
-        Tmp d_woff(wave_off.size() * 8), d_rank(pass_rank.size() * 4);
-        PD_CHECK(hipMemcpyAsync(d_woff.p, wave_off.data(), wave_off.size() * 8, hipMemcpyHostToDevice, st));
+        // first step slot of every ((block, wave), window)
+        std::vector<int64_t> win_off(n_steps);
+        for (size_t bw = 0; bw + 1 < wave_off.size(); ++bw) {
+            int64_t off = wave_off[bw];
+            for (int w = 0; w < P.n_windows; ++w) {
+                win_off[bw * P.n_windows + w] = off;
+                off += (int64_t)P.steps[bw * P.n_windows + w] * P.gpw;
+            }
+        }
+        Tmp d_woff(win_off.size() * 8), d_rank(pass_rank.size() * 4);
+        PD_CHECK(hipMemcpyAsync(d_woff.p, win_off.data(), win_off.size() * 8, hipMemcpyHostToDevice, st));
         PD_CHECK(hipMemcpyAsync(d_rank.p, pass_rank.data(), pass_rank.size() * 4, hipMemcpyHostToDevice, st));
-        if (n_slots > 0)
-            hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n_slots, 64)), dim3(64), 0, st, g, n_slots,
-                               d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, s_val,
-                               static_cast<const uint16_t *>(d_steps16), d_woff.as<int64_t>(), d_rank.as<int>(),
-                               static_cast<uint32_t *>(d_entries));
+        if (n_segments > 0)
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
+                               d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, s_val, d_woff.as<int64_t>(),
+                               d_rank.as<int>(), static_cast<uint32_t *>(d_entries));
         PD_CHECK(hipGetLastError());
         PD_CHECK(hipStreamSynchronize(st));
         P.mptr.swap(mptr);
