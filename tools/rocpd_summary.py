@@ -9,6 +9,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("schpf::", "").replace("void ", "")
     return name[:70]
