@@ -112,8 +112,10 @@ int schpf_create(schpf_ctx **out, int device, void *stream, int dtype, int ncell
 int schpf_destroy(schpf_ctx *ctx);
 
 /* The count matrix X (scipy coo_matrix: X.row, X.col, X.data), any order, duplicates kept
- * as separate observations like the reference (hpf_numba.py:98-112).  Builds both sweep
- * plans and uploads them.  Values must be > 0 and exactly representable in float32. */
+ * as separate observations like the reference (hpf_numba.py:98-112).  Validates on the host,
+ * copies the triples to the device and builds both sweep plans there (the host
+ * builder, SCHPF_DEVICE_PLAN=0, gives the same plans bit for bit).  Values must be > 0 and
+ * exactly representable in float32.  Host pointers are not retained. */
 int schpf_upload_coo(schpf_ctx *ctx, int64_t nnz, const int32_t *row, const int32_t *col,
                      const void *val, int val_kind);
 
