@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libschpf_hip.so")
+LIB_PATH = os.environ.get("SCHPF_LIB_PATH") or os.path.join(_HERE, "libschpf_hip.so")   # override: A/B of two builds
 
 F32, F64 = 0, 1
 XI, THETA, ETA, BETA = 0, 1, 2, 3
