@@ -476,6 +476,39 @@ template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
 // The entry stream runs through a 4-slot register ring: slot i is refilled with step p+4 as
 // soon as step p has been taken out of it, and the ring for the NEXT window is primed before
 // that window's staging barrier, so HBM latency hides behind four steps of math or a staging.
+// sum over nonzeros of x * log(r) - r without a log per nonzero: log(prod r^x) with the product
+// kept as mantissa x 2^exponent.  r^x for counts up to 15 is three squarings and conditional
+// multiplies; larger counts (rare in UMI data) take the log.  One f64 log costs ~80 VALU
+// instructions, this ~25; the rounding error of the running product (one ulp per multiply, a few
+// thousand multiplies per lane) is ~1e-13 absolute on a per-lane sum of order 1e3.
+struct LlhAccumulator {
+    double mant = 1.0, rare = 0.0, rsum = 0.0;
+    int expo = 0;
+    __device__ __forceinline__ void add(double x, double r)
+    {
+        rsum += r;
+        const int xi = (int)x;
+        if (xi > 15 || (double)xi != x) { rare += x * log(r); return; }   // divergent, rare
+        const int e = __builtin_amdgcn_frexp_exp(r);
+        const double m = __builtin_amdgcn_frexp_mant(r);                    // [0.5, 1), or 0 / inf / nan as r
+        expo += xi * e;
+        double p = (xi & 1) ? m : 1.0;
+        const double m2 = m * m;
+        p = (xi & 2) ? p * m2 : p;
+        const double m4 = m2 * m2;
+        p = (xi & 4) ? p * m4 : p;
+        const double m8 = m4 * m4;
+        p = (xi & 8) ? p * m8 : p;
+        const double q = mant * p;                                           // >= 2^-16: no underflow
+        expo += __builtin_amdgcn_frexp_exp(q);
+        mant = __builtin_amdgcn_frexp_mant(q);
+    }
+    __device__ __forceinline__ double total() const
+    {
+        return (double)expo * 0.69314718055994530942 + log(mant) + rare - rsum;
+    }
+};
+
 template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
@@ -502,6 +535,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     for (int k = 0; k < KL; ++k) { tm[k] = T(0); acc[k] = T(0); }
     if (MODE != MODE_RANDOM && live) load_lane<T, NV, LPC>(a.tab_major + (size_t)major * KP, sub, tm);
     double llh = 0.0;
+    LlhAccumulator lacc;   // MODE_LLH in the pipelined path
     bool any_bad = false;
     const T tiny = Vec16<T>::tiny();
     // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
@@ -591,14 +625,14 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
                         load_lane<T, NV, LPC>(win + __umul24(n1, KP), sub, bB);
                         if (MODE == MODE_LLH) {
                             if (LPC == 1) {
-                                if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
-                                if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
+                                if (x0 > T(0)) lacc.add((double)x0, (double)s0);
+                                if (x1 > T(0)) lacc.add((double)x1, (double)s1);
                             } else {
-                                // every lane of the group knows s0 and s1: lane 0 takes the log of the
-                                // first nonzero, lane 1 of the second (the f64 log is the costly part)
+                                // every lane of the group knows s0 and s1: lane 0 takes the first
+                                // nonzero, lane 1 the second
                                 const T sm = (sub & 1) ? s1 : s0;
                                 const T xm = (sub & 1) ? x1 : x0;
-                                if (sub < 2 && xm > T(0)) llh += (double)xm * log((double)sm) - (double)sm;
+                                if (sub < 2 && xm > T(0)) lacc.add((double)xm, (double)sm);
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -699,6 +733,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     }
 
     if (MODE == MODE_LLH) {
+        if (PIPE) llh += lacc.total();
         // which lanes hold a share: all (LPC 1), lanes 0-1 of a group (paired steps), lane 0 (else)
         if (LPC > 1 && !(PAIR ? sub < 2 : sub == 0)) llh = 0.0;
         llh = wave_sum(llh);
