@@ -535,7 +535,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     for (int k = 0; k < KL; ++k) { tm[k] = T(0); acc[k] = T(0); }
     if (MODE != MODE_RANDOM && live) load_lane<T, NV, LPC>(a.tab_major + (size_t)major * KP, sub, tm);
     double llh = 0.0;
-    LlhAccumulator lacc;   // MODE_LLH in the pipelined path
+    LlhAccumulator lacc;   // MODE_LLH
     bool any_bad = false;
     const T tiny = Vec16<T>::tiny();
     // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
@@ -713,7 +713,8 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
 #pragma unroll
                                     for (int k = 0; k < KL; ++k) acc[k] = fma_t(q, b[k], acc[k]);
                                 } else {
-                                    if (x > T(0)) llh += (double)x * log((double)s) - (double)s;
+                                    // wide rows: lane 0 of the group keeps the group's share
+                                    if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
                                 }
                             }
                         }
@@ -733,7 +734,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     }
 
     if (MODE == MODE_LLH) {
-        if (PIPE) llh += lacc.total();
+        llh += lacc.total();   // zero where nothing was added
         // which lanes hold a share: all (LPC 1), lanes 0-1 of a group (paired steps), lane 0 (else)
         if (LPC > 1 && !(PAIR ? sub < 2 : sub == 0)) llh = 0.0;
         llh = wave_sum(llh);
