@@ -27,6 +27,7 @@ struct FillGeometry {
 };
 
 constexpr int kMaxPassGroups = 16;   // lpc = 1: sixteen groups per pass
+constexpr int kJointLimit = 192;     // longest segment of a pass up to which the groups choose jointly
 
 SCHPF_HD inline int fill_bank_class(const FillGeometry &g, int32_t local)
 {
@@ -44,6 +45,23 @@ SCHPF_HD inline int64_t fill_lower_bound(const int32_t *s_minor, int64_t lo, int
     return lo;
 }
 
+// nonzero number t of a row segment -> its half of step slot `step_slot`
+SCHPF_HD inline void fill_store(const FillGeometry &g, uint32_t *entries, uint64_t step_slot, int t, int32_t local, float val)
+{
+    if (g.packed) {
+        uint32_t *e = entries + step_slot * 2;
+        const int sh = (t & 1) * 16;
+        e[0] |= (uint32_t)local << sh;
+        e[1] |= (uint32_t)val << sh;
+    } else {
+        uint32_t *e = entries + step_slot * 4 + (uint64_t)(t & 1) * 2;
+        e[0] = (uint32_t)local;
+        union { float f; uint32_t u; } cv;
+        cv.f = val;
+        e[1] = cv.u;
+    }
+}
+
 // members: m < n_members groups of one pass; slot[m] = group index inside the wave, seg_lo[m] /
 // seg_n[m] = its row's nonzeros of this window in the sorted arrays.  base = first minor row of
 // the window, win_off = first step slot of the window's entries of this (block, wave).
@@ -58,6 +76,26 @@ SCHPF_HD inline void fill_pass(const FillGeometry &g, int n_members, const int *
         for (int c = 0; c < 16; ++c) { cnt[m][c] = 0; cur[m][c] = seg_lo[m]; }
         for (int64_t j = seg_lo[m]; j < seg_lo[m] + seg_n[m]; ++j) cnt[m][fill_bank_class(g, s_minor[j] - base)]++;
         if (seg_n[m] > max_n) max_n = seg_n[m];
+    }
+    if (max_n > kJointLimit) {
+        // long segments (a gene expressed in half of the cells of a window): every member on its own,
+        // wished class (member + t) mod classes, else its fullest -- a fraction of the bookkeeping;
+        // the joint choice below costs O(members^2 + members * classes) per position
+        for (int m = 0; m < n_members; ++m)
+            for (int t = 0; t < seg_n[m]; ++t) {
+                int c = (int)(((unsigned)m + (unsigned)t) & (unsigned)(g.n_classes - 1));
+                if (cnt[m][c] == 0) {
+                    int best = 0;
+                    for (int k = 0; k < g.n_classes; ++k)
+                        if (cnt[m][k] > best) { best = cnt[m][k]; c = k; }
+                }
+                int64_t q = cur[m][c];
+                while (fill_bank_class(g, s_minor[q] - base) != c) ++q;
+                cur[m][c] = q + 1;
+                cnt[m][c]--;
+                fill_store(g, entries, (uint64_t)win_off + (uint64_t)(t >> 1) * g.gpw + slot[m], t, s_minor[q] - base, s_val[q]);
+            }
+        return;
     }
     for (int t = 0; t < max_n; ++t) {
         // members still active at this position, fewest remaining classes first (ties: lower slot)
@@ -85,20 +123,7 @@ SCHPF_HD inline void fill_pass(const FillGeometry &g, int n_members, const int *
             while (fill_bank_class(g, s_minor[q] - base) != c) ++q;   // next unused nonzero of the class, minor order
             cur[m][c] = q + 1;
             cnt[m][c]--;
-            const int32_t mn = s_minor[q];
-            const uint64_t step_slot = (uint64_t)win_off + (uint64_t)(t >> 1) * g.gpw + slot[m];
-            if (g.packed) {
-                uint32_t *e = entries + step_slot * 2;
-                const int sh = (t & 1) * 16;
-                e[0] |= (uint32_t)(mn - base) << sh;
-                e[1] |= (uint32_t)s_val[q] << sh;
-            } else {
-                uint32_t *e = entries + step_slot * 4 + (uint64_t)(t & 1) * 2;
-                e[0] = (uint32_t)(mn - base);
-                union { float f; uint32_t u; } cv;
-                cv.f = s_val[q];
-                e[1] = cv.u;
-            }
+            fill_store(g, entries, (uint64_t)win_off + (uint64_t)(t >> 1) * g.gpw + slot[m], t, s_minor[q] - base, s_val[q]);
         }
     }
 }
