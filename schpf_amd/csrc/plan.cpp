@@ -1,6 +1,5 @@
 // Host-side construction of the sweep plans (see plan.h for the layout).
 #include "plan.h"
-#include "plan_fill.h"
 
 #include <algorithm>
 #include <chrono>
@@ -294,6 +293,54 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 }
 
 
+// LDS-bank-aware order of one row segment (tile plan).  A lane group reads the gathered row with
+// ds_read_b128; the LDS serves 16 lanes (= 16/lpc lane groups, one "pass") per cycle and those
+// reads are conflict-free iff their 16-byte slots differ modulo 16.  A table row occupies
+// `row_slots` slots, so the slot base of local row r is (r * row_slots) mod 16 and its class is
+// base / lpc.  The group with rank j inside its pass wants class (j + t) mod n_classes at position
+// t: if every group of a pass gets its wish, the pass touches each slot once.  Greedy: take the
+// wished class if the segment still has such a nonzero, else from the fullest class.
+// seq[t] = index (within the segment) of the nonzero placed at position t.
+static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_slots, int lpc, int rank,
+                       std::vector<int32_t> &seq, std::vector<int32_t> &scratch)
+{
+    const int n_classes = std::max(1, 16 / std::max(1, lpc));   // a power of two (lpc is)
+    if (n_classes == 1 || n <= 2) {
+        for (int t = 0; t < n; ++t) seq[(size_t)t] = t;
+        return;
+    }
+    // stable counting sort of the segment's positions by class; every class is then handed out
+    // front to back, i.e. in minor order
+    int lpc_shift = 0;
+    while ((1 << lpc_shift) < lpc) ++lpc_shift;
+    const unsigned cmask = (unsigned)n_classes - 1u;
+    int cnt[16] = {0}, head[16];
+    scratch.resize((size_t)n * 2);
+    int32_t *cls = scratch.data(), *pos = scratch.data() + n;
+    for (int i = 0; i < n; ++i) {
+        const unsigned c = ((((unsigned)(seg_minor[i] - base) * (unsigned)row_slots) & 15u) >> lpc_shift) & cmask;
+        cls[i] = (int32_t)c;
+        cnt[c]++;
+    }
+    int run = 0;
+    for (int c = 0; c < n_classes; ++c) { head[c] = run; run += cnt[c]; }
+    {
+        int cur[16];
+        for (int c = 0; c < n_classes; ++c) cur[c] = head[c];
+        for (int i = 0; i < n; ++i) pos[cur[cls[i]]++] = i;
+    }
+    for (int t = 0; t < n; ++t) {
+        int c = (int)(((unsigned)rank + (unsigned)t) & cmask);
+        if (cnt[c] == 0) {
+            int best = 0;
+            for (int k = 0; k < n_classes; ++k)
+                if (cnt[k] > best) { best = cnt[k]; c = k; }
+        }
+        seq[(size_t)t] = pos[head[c]++];
+        cnt[c]--;
+    }
+}
+
 // ---- pieces of the tile plan that do not touch the nonzeros; shared by the host builder below
 // ---- and the device builder (plan_device.hip)
 
@@ -408,6 +455,21 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
     return wave_off.back() + (int64_t)12 * gpw;
 }
 
+// rank of every group of a wave inside its ds_read_b128 pass (16 lanes served per LDS cycle)
+std::vector<int> tile_pass_rank(int lpc, int gpw)
+{
+    std::vector<int> pass_rank((size_t)gpw, 0);
+    static const int pass_of_quad[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};  // lanes 4q..4q+3
+    int seen[4] = {0, 0, 0, 0};
+    for (int g2 = 0; g2 < gpw; ++g2) {
+        const int lane0 = g2 * lpc;
+        if (lpc > 16) { pass_rank[(size_t)g2] = 0; continue; }
+        const int ps = pass_of_quad[lane0 / 4];
+        pass_rank[(size_t)g2] = seen[ps]++;
+    }
+    return pass_rank;
+}
+
 void tile_plan_report(const TilePlanHost &P)
 {
     // where the stored slots go: nonzeros / sliced-ELL padding inside a wave / waiting at the
@@ -503,42 +565,50 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     parallel_for(total_padded * epw, nth, [&](int64_t b, int64_t e, int) {
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
-    // fill: per (block, wave, window, LDS pass) the member groups' segments are dealt to the steps
-    // jointly, in an LDS-bank-aware order (plan_fill.h; the device builder runs the same routine)
-    FillGeometry fg{};
-    fg.gpw = gpw; fg.win_rows = win_rows; fg.row_slots = row_slots; fg.packed = packed ? 1 : 0;
-    fg.lpc_shift = 0;
-    while ((1 << fg.lpc_shift) < lpc) ++fg.lpc_shift;
-    fg.n_classes = row_slots > 0 ? std::max(1, 16 / std::max(1, lpc)) : 1;
+    // fill: walk each row's nonzeros in minor order; position inside its window segment = t
+    const std::vector<int> pass_rank = tile_pass_rank(lpc, gpw);
     parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
-        for (int64_t b = b0; b < b1; ++b)
-            for (int v = 0; v < wpb; ++v) {
-                const size_t bw = (size_t)b * wpb + v;
+        std::vector<int64_t> win_off((size_t)W);
+        std::vector<int32_t> seq;
+        std::vector<int32_t> buckets;   // scratch of bank_order
+        for (int64_t b = b0; b < b1; ++b) {
+            for (int g = 0; g < gpb; ++g) {
+                const int32_t row = P.block_rows[(size_t)b * gpb + g];
+                if (row < 0) continue;
+                const size_t bw = (size_t)b * wpb + g / gpw;
                 int64_t off = wave_off[bw];
-                for (int w = 0; w < W; ++w) {
-                    const int32_t base = w * win_rows;
-                    for (int ps = 0; ps < 4; ++ps) {
-                        int slot[kMaxPassGroups], seg_n[kMaxPassGroups], n_members = 0;
-                        int64_t seg_lo[kMaxPassGroups];
-                        for (int s = 0; s < gpw; ++s) {
-                            if (fill_pass_of_slot(s, lpc) != ps) continue;
-                            const int32_t row = P.block_rows[(size_t)b * gpb + (size_t)v * gpw + s];
-                            if (row < 0) continue;
-                            const int64_t r0 = mptr[row], r1 = mptr[(size_t)row + 1];
-                            if (r0 == r1) continue;
-                            const int64_t lo = fill_lower_bound(s_minor.data(), r0, r1, (int64_t)base);
-                            const int64_t hi = fill_lower_bound(s_minor.data(), lo, r1, (int64_t)base + win_rows);
-                            if (hi == lo) continue;
-                            slot[n_members] = s; seg_lo[n_members] = lo; seg_n[n_members] = (int)(hi - lo);
-                            ++n_members;
+                for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += (int64_t)P.steps[bw * W + w] * gpw; }
+                const int slot = g % gpw;
+                // one window segment at a time; inside it the nonzeros may be taken in any order,
+                // so they are dealt to the steps in an LDS-bank-aware order (see bank_order)
+                int64_t j = mptr[row];
+                const int64_t end = mptr[(size_t)row + 1];
+                while (j < end) {
+                    const int32_t w = s_minor[(size_t)j] / win_rows;
+                    const int64_t bound = ((int64_t)w + 1) * win_rows;
+                    int64_t s = j;
+                    while (j < end && s_minor[(size_t)j] < bound) ++j;
+                    const int n = (int)(j - s);
+                    seq.resize((size_t)n);
+                    bank_order(s_minor.data() + s, n, w * win_rows, row_slots, lpc, pass_rank[(size_t)slot], seq, buckets);
+                    for (int t = 0; t < n; ++t) {
+                        const int64_t src = s + seq[(size_t)t];
+                        const int32_t mn = s_minor[(size_t)src];
+                        const size_t step_slot = (size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot;
+                        if (packed) {
+                            uint32_t *e = P.entries.data() + step_slot * 2;
+                            const int sh = (t & 1) * 16;
+                            e[0] |= (uint32_t)(mn - w * win_rows) << sh;
+                            e[1] |= (uint32_t)s_val[(size_t)src] << sh;
+                        } else {
+                            uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
+                            e[0] = (uint32_t)(mn - w * win_rows);
+                            e[1] = f2u(s_val[(size_t)src]);
                         }
-                        if (n_members)
-                            fill_pass(fg, n_members, slot, seg_lo, seg_n, base, off, s_minor.data(), s_val.data(),
-                                      P.entries.data());
                     }
-                    off += (int64_t)P.steps[bw * W + w] * gpw;
                 }
             }
+        }
     });
     if (verbose) {
         fprintf(stderr, "[schpf_hip]     sort %.3f s, sorted copies %.3f s, steps %.3f s, alloc+fill %.3f s\n", t1 - t0,

@@ -154,6 +154,7 @@ void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, BigVec<in
 void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, int lpc, int waves_per_block,
                      int win_rows, int target_tasks, const int64_t *mptr);
 int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off);
+std::vector<int> tile_pass_rank(int lpc, int gpw);
 void tile_plan_report(const TilePlanHost &P);
 
 // the (major, minor) / (minor, major) order of a host COO (one threaded scan)

@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "plan.h"
-#include "plan_fill.h"
 
 namespace schpf {
 namespace {
@@ -109,34 +108,75 @@ __global__ void steps_kernel(Geometry g, int64_t n_slots, const int32_t *__restr
     atomicMax(steps32 + ((size_t)b * g.wpb + v) * g.W + w, (unsigned)steps);
 }
 
-// fill: one thread per (block, wave, window, LDS pass); the routine is plan_fill.h::fill_pass, the
-// same code the host builder runs
-__global__ void fill_kernel(FillGeometry fg, int lpc, int gpb, int wpb, int W, int64_t n_blocks,
-                            const int32_t *__restrict__ block_rows, const int64_t *__restrict__ mptr,
-                            const int32_t *__restrict__ s_minor, const float *__restrict__ s_val,
-                            const int64_t *__restrict__ win_off, uint32_t *__restrict__ entries)
+__device__ __forceinline__ int bank_class(const Geometry &g, int32_t local)
+{
+    return (int)(((((unsigned)local * (unsigned)g.row_slots) & 15u) >> g.lpc_shift) & (unsigned)(g.n_classes - 1));
+}
+
+// fill, one thread per (row, window) segment: the segment's nonzeros are dealt to the steps in the
+// LDS-bank-aware order of plan.cpp::bank_order (wished class (rank + t) mod classes, else the
+// fullest class; inside a class in minor order).  win_off[(block, wave), window] = first step
+// slot of that window's entries.
+__global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restrict__ block_rows,
+                            const int64_t *__restrict__ mptr, const int32_t *__restrict__ s_minor,
+                            const float *__restrict__ s_val, const int64_t *__restrict__ win_off,
+                            const int *__restrict__ pass_rank, uint32_t *__restrict__ entries)
 {
     const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (id >= n_blocks * wpb * W * 4) return;
-    const int ps = (int)(id & 3);
-    const int w = (int)((id >> 2) % W);
-    const int64_t bw = (id >> 2) / W;   // block * wpb + wave
-    const int32_t base = w * fg.win_rows;
-    int slot[kMaxPassGroups], seg_n[kMaxPassGroups], n_members = 0;
-    int64_t seg_lo[kMaxPassGroups];
-    for (int s = 0; s < fg.gpw; ++s) {
-        if (fill_pass_of_slot(s, lpc) != ps) continue;
-        const int32_t row = block_rows[bw * fg.gpw + s];   // (block * wpb + wave) * gpw + s == block * gpb + wave * gpw + s
-        if (row < 0) continue;
-        const int64_t r0 = mptr[row], r1 = mptr[row + 1];
-        if (r0 == r1) continue;
-        const int64_t lo = fill_lower_bound(s_minor, r0, r1, (int64_t)base);
-        const int64_t hi = fill_lower_bound(s_minor, lo, r1, (int64_t)base + fg.win_rows);
-        if (hi == lo) continue;
-        slot[n_members] = s; seg_lo[n_members] = lo; seg_n[n_members] = (int)(hi - lo);
-        ++n_members;
+    if (id >= n_slots * g.W) return;
+    const int64_t slot = id / g.W;
+    const int w = (int)(id % g.W);
+    const int32_t row = block_rows[slot];
+    if (row < 0) return;
+    const int64_t r0 = mptr[row], r1 = mptr[row + 1];
+    if (r0 == r1) return;
+    const int32_t base = w * g.win_rows;
+    const int64_t s = lower_bound_minor(s_minor, r0, r1, (int64_t)base);
+    const int64_t e_ = lower_bound_minor(s_minor, s, r1, (int64_t)base + g.win_rows);
+    const int n = (int)(e_ - s);
+    if (n == 0) return;
+    const int64_t b = slot / g.gpb;
+    const int gi = (int)(slot % g.gpb);
+    const int gslot = gi % g.gpw;
+    const size_t bw = (size_t)b * g.wpb + gi / g.gpw;
+    const int rank = pass_rank[gslot];
+    const int64_t off = win_off[bw * g.W + w];
+    const bool ordered = g.n_classes > 1 && n > 2;
+    int cnt[16];
+    int64_t cur[16];
+    for (int c = 0; c < 16; ++c) { cnt[c] = 0; cur[c] = s; }
+    if (ordered)
+        for (int64_t j = s; j < e_; ++j) cnt[bank_class(g, s_minor[j] - base)]++;
+    for (int t = 0; t < n; ++t) {
+        int64_t src;
+        if (!ordered) {
+            src = s + t;
+        } else {
+            int c = (int)(((unsigned)rank + (unsigned)t) & (unsigned)(g.n_classes - 1));
+            if (cnt[c] == 0) {
+                int best = 0;
+                for (int k = 0; k < g.n_classes; ++k)
+                    if (cnt[k] > best) { best = cnt[k]; c = k; }
+            }
+            int64_t q = cur[c];
+            while (bank_class(g, s_minor[q] - base) != c) ++q;   // next unused nonzero of class c, in minor order
+            src = q;
+            cur[c] = q + 1;
+            cnt[c]--;
+        }
+        const int32_t mn = s_minor[src];
+        const size_t step_slot = (size_t)off + (size_t)(t >> 1) * g.gpw + gslot;
+        if (g.packed) {
+            uint32_t *e = entries + step_slot * 2;
+            const int sh = (t & 1) * 16;
+            e[0] |= (uint32_t)(mn - base) << sh;
+            e[1] |= (uint32_t)s_val[src] << sh;
+        } else {
+            uint32_t *e = entries + step_slot * 4 + (size_t)(t & 1) * 2;
+            e[0] = (uint32_t)(mn - base);
+            e[1] = __float_as_uint(s_val[src]);
+        }
     }
-    if (n_members) fill_pass(fg, n_members, slot, seg_lo, seg_n, base, win_off[bw * W + w], s_minor, s_val, entries);
 }
 
 inline unsigned grid_for(int64_t n, int threads)
@@ -231,6 +271,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         P.packed = allow_packed && win_rows <= 65536 && packed_ok;
         g.packed = P.packed ? 1 : 0;
         const int epw = P.packed ? 2 : 4;
+        const std::vector<int> pass_rank = tile_pass_rank(lpc, P.gpw);
 
         // ---- 6. fill
         void *d_entries = nullptr, *d_steps16 = nullptr;
@@ -251,16 +292,13 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
                 off += (int64_t)P.steps[bw * P.n_windows + w] * P.gpw;
             }
         }
-        Tmp d_woff(win_off.size() * 8);
+        Tmp d_woff(win_off.size() * 8), d_rank(pass_rank.size() * 4);
         PD_CHECK(hipMemcpyAsync(d_woff.p, win_off.data(), win_off.size() * 8, hipMemcpyHostToDevice, st));
-        FillGeometry fg{};
-        fg.gpw = P.gpw; fg.win_rows = win_rows; fg.row_slots = row_slots; fg.packed = g.packed;
-        fg.lpc_shift = g.lpc_shift; fg.n_classes = g.n_classes;
-        const int64_t n_fill = P.n_blocks * P.wpb * P.n_windows * 4;
-        if (n_fill > 0)
-            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_fill + 63) / 64)), dim3(64), 0, st, fg, lpc, P.gpb,
-                               P.wpb, P.n_windows, P.n_blocks, d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor,
-                               s_val, d_woff.as<int64_t>(), static_cast<uint32_t *>(d_entries));
+        PD_CHECK(hipMemcpyAsync(d_rank.p, pass_rank.data(), pass_rank.size() * 4, hipMemcpyHostToDevice, st));
+        if (n_segments > 0)
+            hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
+                               d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, s_val, d_woff.as<int64_t>(),
+                               d_rank.as<int>(), static_cast<uint32_t *>(d_entries));
         PD_CHECK(hipGetLastError());
         PD_CHECK(hipStreamSynchronize(st));
         P.mptr.swap(mptr);
