@@ -200,8 +200,8 @@ def main():
     n_local = N // world + (1 if rank < N % world else 0)
     X = synthetic_block(n_local, G, density, seed=42 + 1000 * rank)
 
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = DeviceCAVI(n_local, G, K, dtype=dtype, device=local_rank, stream=stream)
+    # the engine enqueues on a stream of its own; ShardedCAVI orders the collective with it
+    eng = DeviceCAVI(n_local, G, K, dtype=dtype, device=local_rank)
     t_up = time.perf_counter()
     init_engine(eng, X, K, dtype)
     upload_s = time.perf_counter() - t_up

@@ -104,9 +104,12 @@ int schpf_capacity_rate_update(int dtype, int n, int nfactors, const void *shape
  * The engine: device-resident state for scHPF._fit's loop (scHPF_.py:642-715).
  * ------------------------------------------------------------------------------- */
 
-/* Create a context on HIP device `device`.  `stream` is a hipStream_t to enqueue on
- * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the library create one.
+/* Create a context on HIP device `device`.  `stream`: a hipStream_t to enqueue on; NULL lets the
+ * library create a (non-blocking) stream of its own; SCHPF_STREAM_DEFAULT selects the device's
+ * null stream -- torch.cuda.current_stream().cuda_stream is 0 for it, which a caller must map to
+ * SCHPF_STREAM_DEFAULT when it wants its collectives ordered with the engine's kernels.
  * ncells is the number of LOCAL cells when cells are sharded. */
+#define SCHPF_STREAM_DEFAULT ((void *)1)
 int schpf_create(schpf_ctx **out, int device, void *stream, int dtype, int ncells, int ngenes,
                  int nfactors);
 int schpf_destroy(schpf_ctx *ctx);
@@ -114,8 +117,11 @@ int schpf_destroy(schpf_ctx *ctx);
 /* The count matrix X (scipy coo_matrix: X.row, X.col, X.data), any order, duplicates kept
  * as separate observations like the reference (hpf_numba.py:98-112).  Validates on the host,
  * copies the triples to the device and builds both sweep plans there (the host
- * builder, SCHPF_DEVICE_PLAN=0, gives the same plans bit for bit).  Values must be > 0 and
- * exactly representable in float32.  Host pointers are not retained. */
+ * builder, SCHPF_DEVICE_PLAN=0, gives the same plans bit for bit).  Values must be finite and
+ * >= 0 -- the reference takes any X.data (hpf_numba.py:98-112).  They are stored as float32: UMI
+ * counts are exact; other values are rounded (relative 6e-8) and counted in schpf_upload_info.
+ * Explicitly stored zeros add nothing to the updates and -r each to the loss, as in the reference
+ * (hpf_numba.py:43-50).  Host pointers are not retained. */
 int schpf_upload_coo(schpf_ctx *ctx, int64_t nnz, const int32_t *row, const int32_t *col,
                      const void *val, int val_kind);
 
@@ -156,6 +162,10 @@ int schpf_loss_terms(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64
 
 int schpf_synchronize(schpf_ctx *ctx);
 
+/* The hipStream_t the context enqueues on (0 = the null stream), so that a caller can order its
+ * own work -- the all-reduce of the exchange buffer -- with the engine's kernels. */
+int schpf_stream_handle(schpf_ctx *ctx, void **stream);
+
 /* HIP-event timing of the sweep kernel launches on the context's stream (bench.py).
  * ms[0] = cell sweep, ms[1] = gene sweep, ms[2] = loss sweep, ms[3] = gamma updates;
  * launches[] likewise.  When both sweeps of an iteration run as ONE launch (the default for
@@ -167,6 +177,10 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
 /* Plan facts for reports: info[0..] = KP, KL, LPC, chunk_len, windows_cell, windows_gene,
  * n_chunks_cell, n_chunks_gene, n_waves_cell, n_waves_gene, stored entry slots cell, gene */
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]);
+
+/* Facts about the uploaded matrix: info = {nnz, values that were rounded to float32, explicitly
+ * stored zeros, 1 if the packed 8-byte entry format is in use}. */
+int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]);
 
 /* Row sums (per cell) and column sums (per gene) of a host COO matrix: the inputs of the empirical
  * hyperparameters bp = ap * mean/var(cell sums), dp = cp * mean/var(gene sums)

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("SCHPF_LIB_PATH") or os.path.join(_HERE, "libschpf_hip
 F32, F64 = 0, 1
 XI, THETA, ETA, BETA = 0, 1, 2, 3
 VAL_I32, VAL_I64, VAL_F32, VAL_F64 = 0, 1, 2, 3
+STREAM_DEFAULT = 1   # SCHPF_STREAM_DEFAULT: the device's null stream
 FREEZE_GENES, SIMULTANEOUS, SHARDED, CELLS_FIRST, LOCAL_GENE, LOCAL_CELL = 1, 2, 4, 8, 16, 32
 
 _vp = ctypes.c_void_p
@@ -47,9 +48,11 @@ SIGNATURES = {
     "schpf_step_finish": [_vp, ctypes.c_uint],
     "schpf_loss_terms": [_vp, _dblp, _dblp, _i64p],
     "schpf_synchronize": [_vp],
+    "schpf_stream_handle": [_vp, ctypes.POINTER(_vp)],
     "schpf_profile_enable": [_vp, _int],
     "schpf_profile_read": [_vp, _dblp, _i64p],
     "schpf_plan_info": [_vp, _i64p],
+    "schpf_upload_info": [_vp, _i64p],
     "schpf_coo_marginals": [_i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp],
     "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64p],

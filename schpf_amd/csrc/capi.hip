@@ -171,6 +171,7 @@ struct schpf_ctx {
     virtual void exchange(void **p, int64_t *count) = 0;
     virtual void loss_terms(double *llh, double *gl, int64_t *nnz) = 0;
     virtual void plan_info(int64_t info[12]) = 0;
+    virtual void upload_info(int64_t info[4]) = 0;
     double a = 0.3, c = 0.3, bp = 1.0, dp = 1.0;
     Profiler prof;
 };
@@ -194,6 +195,8 @@ template <typename T> struct Engine final : schpf_ctx {
     bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
     double gammaln_sum = 0.0;
+    int64_t n_rounded = 0, n_zero = 0;              // upload facts: values rounded to float32; stored zeros
+    DevBuf zero_row, zero_col;                      // positions of explicitly stored zeros (loss only)
     bool have_coo = false;
     bool dirty_theta = true, dirty_beta = true;
     int pending_init = 0;  // 0 none, 1 dense accumulators, 2 chunk partials
@@ -203,7 +206,10 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         device = device_; dtype = dtype_; N = N_; G = G_; K = K_;
         HIPCHK(hipSetDevice(device));
-        if (stream_) stream = (hipStream_t)stream_;
+        // NULL: a stream of our own; SCHPF_STREAM_DEFAULT: the device's null stream (what
+        // torch.cuda.current_stream() is unless the caller switched streams); else the given handle
+        if (stream_ == SCHPF_STREAM_DEFAULT) stream = nullptr;
+        else if (stream_) stream = (hipStream_t)stream_;
         else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
         choose_config();
         const size_t s = sizeof(T);
@@ -475,11 +481,15 @@ template <typename T> struct Engine final : schpf_ctx {
         const bool verbose = env_int("SCHPF_VERBOSE", 0) != 0;
         const double t_start = now_s();
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
+        if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
         schpf::BigVec<float> v((size_t)nnz_);   // no serial zero-fill: written by the threaded pass below
         bool packed_ok = true;
+        n_rounded = 0;
+        std::vector<int32_t> zrow, zcol;         // explicitly stored zeros (rare): see zero_rate_sum()
         {   // validate + convert, in parallel slabs (first offending entry per slab is reported)
             const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(schpf::host_threads(), nnz_ / 65536 + 1));
-            std::vector<int64_t> bad_val((size_t)nth, -1), bad_idx((size_t)nth, -1);
+            std::vector<int64_t> bad_val((size_t)nth, -1), bad_idx((size_t)nth, -1), rounded((size_t)nth, 0);
+            std::vector<std::vector<int32_t>> zr((size_t)nth), zc((size_t)nth);
             std::vector<char> wide((size_t)nth, 0);   // a count that does not fit the packed 16-bit entry format
             std::vector<std::thread> th;
             for (int t = 0; t < nth; ++t)
@@ -494,25 +504,33 @@ template <typename T> struct Engine final : schpf_ctx {
                         default: d = ((const double *)val)[i]; break;
                         }
                         const float f = (float)d;
-                        if ((!(d > 0.0) || (double)f != d) && bad_val[(size_t)t] < 0) bad_val[(size_t)t] = i;
+                        // the reference takes any X.data (hpf_numba.py:98-112 only multiplies by it); what
+                        // cannot be a Poisson observation at all (negative, NaN, inf) is refused
+                        if (!(d >= 0.0 && f <= 3.0e38f) && bad_val[(size_t)t] < 0) bad_val[(size_t)t] = i;
                         if ((row[i] < 0 || row[i] >= N || col[i] < 0 || col[i] >= G) && bad_idx[(size_t)t] < 0)
                             bad_idx[(size_t)t] = i;
+                        else if (d == 0.0) { zr[(size_t)t].push_back(row[i]); zc[(size_t)t].push_back(col[i]); }
+                        if ((double)f != d) ++rounded[(size_t)t];
                         v[(size_t)i] = f;
                         if (!(f <= 65535.0f) || f != (float)(uint32_t)f) wide[(size_t)t] = 1;
                     }
                 });
             for (auto &x : th) x.join();
-            if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
             for (int t = 0; t < nth; ++t) packed_ok = packed_ok && !wide[(size_t)t];
             for (int t = 0; t < nth; ++t) {
                 if (bad_idx[(size_t)t] >= 0)
                     throw std::invalid_argument("COO index out of range at entry " + std::to_string(bad_idx[(size_t)t]));
                 if (bad_val[(size_t)t] >= 0)
-                    throw std::invalid_argument("X.data must be > 0 and exactly representable in float32 "
-                                                "(UMI counts are); offending entry " +
+                    throw std::invalid_argument("X.data must be finite and >= 0; offending entry " +
                                                 std::to_string(bad_val[(size_t)t]));
+                n_rounded += rounded[(size_t)t];
+                zrow.insert(zrow.end(), zr[(size_t)t].begin(), zr[(size_t)t].end());
+                zcol.insert(zcol.end(), zc[(size_t)t].begin(), zc[(size_t)t].end());
             }
         }
+        n_zero = (int64_t)zrow.size();
+        upload(zero_row, zrow, stream);
+        upload(zero_col, zcol, stream);
         const double t_valid = now_s();
         nnz = nnz_;
         const int cpw = 64 / LPC;
@@ -887,13 +905,25 @@ template <typename T> struct Engine final : schpf_ctx {
         run_sweep(0, schpf::MODE_LLH);
         HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(), use_tile ? tcell.n_wave_out : cell.n_waves,
                                          scalars.as<double>(), stream));
+        // explicitly stored zeros look like padding to the sweeps (weight 0, which is what they
+        // contribute to the shape updates, hpf_numba.py:97-112), but the reference's loss counts
+        // them: x log r - r - lgamma(x+1) = -r (hpf_numba.py:43-50)
+        if (n_zero > 0)
+            HIPCHK(schpf::launch_zero_rate_sum<T>(zero_row.as<int>(), zero_col.as<int>(), n_zero, th_e.as<T>(),
+                                                  be_e.as<T>(), K, KP, scalars.as<double>() + 2, stream));
         tm.stop();
-        double h = 0.0;
-        HIPCHK(hipMemcpyAsync(&h, scalars.p, sizeof(double), hipMemcpyDeviceToHost, stream));
+        double h[3] = {0.0, 0.0, 0.0};
+        HIPCHK(hipMemcpyAsync(h, scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        *llh = h;
+        *llh = n_zero > 0 ? h[0] - h[2] : h[0];
         *gl = gammaln_sum;
         *nnz_out = nnz;
+    }
+
+    void upload_info(int64_t info[4]) override
+    {
+        info[0] = nnz; info[1] = n_rounded; info[2] = n_zero;
+        info[3] = use_tile ? (tcell.packed ? 1 : 0) : 0;
     }
 
     void plan_info(int64_t info[12]) override
@@ -1173,6 +1203,11 @@ int schpf_loss_terms(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64
     CTX_CALL(ctx->loss_terms(llh_sum, gammaln_sum, nnz));
 }
 int schpf_synchronize(schpf_ctx *ctx) { CTX_CALL(HIPCHK(hipStreamSynchronize(ctx->stream))); }
+int schpf_stream_handle(schpf_ctx *ctx, void **stream)
+{
+    if (!stream) return fail("stream is NULL");
+    CTX_CALL(*stream = (void *)ctx->stream);
+}
 
 int schpf_profile_enable(schpf_ctx *ctx, int enable) { CTX_CALL(ctx->prof.on = enable != 0); }
 int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
@@ -1191,6 +1226,7 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
         ctx->prof.recs.clear());
 }
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]) { CTX_CALL(ctx->plan_info(info)); }
+int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]) { CTX_CALL(ctx->upload_info(info)); }
 
 int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind,
                         int ncells, int ngenes, double *row_sums, double *col_sums)

@@ -85,6 +85,9 @@ hipError_t launch_combine_strided(const T *partials, const int *pfirst, const in
 hipError_t launch_sum_doubles(const double *v, int64_t n, double *out, hipStream_t st);
 hipError_t launch_gammaln_sum(const float *x, int64_t n, double *block_out, int nblocks, hipStream_t st);
 template <typename T>
+hipError_t launch_zero_rate_sum(const int *row, const int *col, int64_t n, const T *et, const T *eb, int K, int KP,
+                                double *out, hipStream_t st);
+template <typename T>
 hipError_t launch_segment_sum(const double *xphi, const int *order, const int64_t *mptr, int n, int K, T *out,
                               hipStream_t st);
 

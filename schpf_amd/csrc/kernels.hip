@@ -231,6 +231,32 @@ __global__ __launch_bounds__(256) void gammaln_sum_kernel(const float *__restric
     if (threadIdx.x == 0) block_out[blockIdx.x] = red[0];
 }
 
+// sum over the explicitly stored zeros of r = sum_k E[theta_ik] E[beta_gk]: their whole term of the
+// loss (hpf_numba.py:43-50 with x = 0).  One block, fixed order; real matrices have none or few.
+template <typename T>
+__global__ __launch_bounds__(256) void zero_rate_sum_kernel(const int *__restrict__ row, const int *__restrict__ col,
+                                                            int64_t n, const T *__restrict__ et,
+                                                            const T *__restrict__ eb, int K, int KP,
+                                                            double *__restrict__ out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const T *t = et + (size_t)row[i] * KP;
+        const T *b = eb + (size_t)col[i] * KP;
+        T r = T(0);
+        for (int k = 0; k < K; ++k) r += t[k] * b[k];
+        s += (double)r;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 // ------------------------------------------------------ t = 0 random responsibilities
 // scHPF_.py:652-655: X*phi with phi ~ Dirichlet(1_K), drawn by the caller (NumPy global
 // RNG, for seed parity) and uploaded as (nnz, K) float64 in the caller's COO order.
@@ -439,6 +465,13 @@ hipError_t launch_gammaln_sum(const float *x, int64_t n, double *block_out, int 
     return hipGetLastError();
 }
 template <typename T>
+hipError_t launch_zero_rate_sum(const int *row, const int *col, int64_t n, const T *et, const T *eb, int K, int KP,
+                                double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL((zero_rate_sum_kernel<T>), dim3(1), dim3(256), 0, st, row, col, n, et, eb, K, KP, out);
+    return hipGetLastError();
+}
+template <typename T>
 hipError_t launch_segment_sum(const double *xphi, const int *order, const int64_t *mptr, int n, int K, T *out,
                               hipStream_t st)
 {
@@ -523,6 +556,8 @@ hipError_t launch_gammaln_array(const double *x, int64_t n, double *out, hipStre
     template hipError_t launch_combine_partials<T>(const T *, const int *, int, int, int, T *, hipStream_t);   \
     template hipError_t launch_combine_strided<T>(const T *, const int *, const int *, int64_t, int, int, int,  \
                                                   T *, hipStream_t);                                           \
+    template hipError_t launch_zero_rate_sum<T>(const int *, const int *, int64_t, const T *, const T *, int,  \
+                                                int, double *, hipStream_t);                                  \
     template hipError_t launch_segment_sum<T>(const double *, const int *, const int64_t *, int, int, T *,     \
                                               hipStream_t);                                                    \
     template hipError_t launch_elog<T>(const T *, const T *, int64_t, T *, hipStream_t);                       \

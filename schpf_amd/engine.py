@@ -34,7 +34,10 @@ class DeviceCAVI(object):
         HIP device ordinal.
     stream : int or None
         a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream) to
-        enqueue on; None lets the library create its own stream.
+        enqueue on; None lets the library create its own stream.  0 -- what torch
+        reports for its default stream -- means the device's null stream, so that
+        work torch enqueues on its current stream (collectives) is ordered with the
+        engine's kernels.
     """
 
     def __init__(self, ncells, ngenes, nfactors, dtype=np.float64, device=0, stream=None):
@@ -50,8 +53,12 @@ class DeviceCAVI(object):
         self.ncells, self.ngenes, self.nfactors = int(ncells), int(ngenes), int(nfactors)
         self.nnz = 0
         handle = ctypes.c_void_p()
+        if stream is None:
+            stream_arg = None
+        else:
+            stream_arg = int(stream) or _lib.STREAM_DEFAULT
         _lib.check(self._lib.schpf_create(ctypes.byref(handle), int(device),
-                                          ctypes.c_void_p(stream or 0), code,
+                                          ctypes.c_void_p(stream_arg), code,
                                           self.ncells, self.ngenes, self.nfactors))
         self._h = handle
 
@@ -87,6 +94,18 @@ class DeviceCAVI(object):
         _lib.check(self._lib.schpf_upload_coo(self._h, data.shape[0], _p(row), _p(col), _p(data),
                                               _VAL_KINDS[data.dtype]))
         self.nnz = int(data.shape[0])
+        info = self.upload_info()
+        if info["rounded"]:
+            import warnings
+            warnings.warn("%d of %d values of X.data are not exactly representable in float32 and were "
+                          "rounded (relative error <= 6e-8); counts are stored as float32 on the device"
+                          % (info["rounded"], info["nnz"]), RuntimeWarning, stacklevel=2)
+
+    def upload_info(self):
+        """{'nnz', 'rounded' (values rounded to float32), 'zeros' (explicitly stored), 'packed'}."""
+        info = (ctypes.c_int64 * 4)()
+        _lib.check(self._lib.schpf_upload_info(self._h, info))
+        return dict(zip(("nnz", "rounded", "zeros", "packed"), [int(v) for v in info]))
 
     def set_hypers(self, a, c, bp, dp):
         _lib.check(self._lib.schpf_set_hypers(self._h, float(a), float(c), float(bp), float(dp)))
@@ -161,6 +180,12 @@ class DeviceCAVI(object):
 
     def synchronize(self):
         _lib.check(self._lib.schpf_synchronize(self._h))
+
+    def stream_handle(self):
+        """The hipStream_t (as an int; 0 = null stream) the engine enqueues on."""
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.schpf_stream_handle(self._h, ctypes.byref(h)))
+        return h.value or 0
 
     # ----------------------------------------------------------------- reporting
     def profile(self, enable=True):

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["psi", "cgammaln", "compute_pois_llh", "compute_Xphi_data",
+__all__ = ["psi", "cgammaln", "compute_pois_llh", "compute_Xphi_data", "compute_Xphi_data_numpy",
            "compute_loading_shape_update", "compute_loading_rate_update",
            "compute_capacity_rate_update", "coo_marginals"]
 
@@ -86,6 +86,17 @@ def compute_Xphi_data(X_data, X_row, X_col, theta_vi_shape, theta_vi_rate,
     """X * phi, (nnz, K) (hpf_numba.py:54-114)."""
     return _coo_call(_lib.load().schpf_xphi, True, X_data, X_row, X_col,
                      theta_vi_shape, theta_vi_rate, beta_vi_shape, beta_vi_rate)
+
+
+def compute_Xphi_data_numpy(X, theta, beta, theta_ix=None):
+    """X * phi from a COO matrix and two HPF_Gamma-like objects (.vi_shape / .vi_rate), the sixth
+    callable of the reference's operator module (hpf_numba.py:117-125; its numpy fallback for
+    single_process=True).  `theta_ix` selects the rows of theta that X's rows refer to (the
+    minibatch case, scHPF_.py:658-660).  Same device kernel as compute_Xphi_data."""
+    ths, thr = theta.vi_shape, theta.vi_rate
+    if theta_ix is not None:
+        ths, thr = ths[theta_ix], thr[theta_ix]
+    return compute_Xphi_data(X.data, X.row, X.col, ths, thr, beta.vi_shape, beta.vi_rate)
 
 
 def compute_loading_shape_update(Xphi_data, X_keep, nkeep, shape_prior):

@@ -67,6 +67,22 @@ class ShardedCAVI(object):
         self.engine = engine
         self.exchange = exchange_tensor
         self.group = group
+        # Stream ordering.  torch.distributed orders a collective with torch's CURRENT stream only
+        # (the process group's own stream waits for an event recorded there, and work.wait() makes
+        # the current stream wait for the collective).  The engine's kernels run on the engine's
+        # stream, so that stream is made torch's current stream around every collective: the
+        # all-reduce then starts after the packing kernel and step_finish after the all-reduce.
+        self._stream_ctx = None
+        if getattr(exchange_tensor, "is_cuda", False) and hasattr(engine, "stream_handle"):
+            import torch
+            h = engine.stream_handle()
+            dev = exchange_tensor.device
+            stream = torch.cuda.default_stream(dev) if h == 0 else torch.cuda.ExternalStream(h, device=dev)
+            self._stream_ctx = lambda: torch.cuda.stream(stream)
+
+    def _on_engine_stream(self):
+        import contextlib
+        return self._stream_ctx() if self._stream_ctx is not None else contextlib.nullcontext()
 
     def step(self, freeze_genes=False, simultaneous=False):
         if freeze_genes:                       # nothing to exchange
@@ -75,9 +91,11 @@ class ShardedCAVI(object):
             return
         # gene-side sweep -> start the all-reduce of its sums -> cell-side sweep runs under it
         self.engine.step_local(simultaneous=simultaneous, side="gene")
-        work = self.dist.all_reduce(self.exchange, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.engine.step_local(simultaneous=simultaneous, side="cell")
-        work.wait()
+        with self._on_engine_stream():
+            work = self.dist.all_reduce(self.exchange, op=self.dist.ReduceOp.SUM, group=self.group,
+                                        async_op=True)
+            self.engine.step_local(simultaneous=simultaneous, side="cell")
+            work.wait()
         self.engine.step_finish(simultaneous=simultaneous)
 
     def mean_negative_pois_llh(self):

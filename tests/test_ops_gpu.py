@@ -47,6 +47,27 @@ def test_xphi_golden(hip, ops):
     assert_allclose(got.sum(1), ops["x"], rtol=1e-6 if dt == np.float32 else 1e-13)
 
 
+def test_xphi_numpy_entry_point_golden(hip, ops):
+    """compute_Xphi_data_numpy(X, theta, beta, theta_ix=None), the sixth callable of the seam
+    (reference hpf_numba.py:117-125): HPF_Gamma arguments, optional row selection."""
+    from scipy.sparse import coo_matrix
+    from schpf import HPF_Gamma
+    import schpf.hpf_numba as seam
+    assert seam.compute_Xphi_data_numpy is hip.compute_Xphi_data_numpy
+    dt = ops["theta_shape"].dtype
+    X = coo_matrix((ops["x"], (ops["row"], ops["col"])), shape=tuple(int(v) for v in ops["shape"]))
+    theta = HPF_Gamma(ops["theta_shape"], ops["theta_rate"])
+    beta = HPF_Gamma(ops["beta_shape"], ops["beta_rate"])
+    got = hip.compute_Xphi_data_numpy(X, theta, beta)
+    assert_allclose(got, ops["xphi_numpy"], rtol=_rt(dt), atol=0)
+    # theta_ix: X's rows index into a selection of theta's rows (the minibatch call, scHPF_.py:658-660)
+    perm = np.random.RandomState(0).permutation(X.shape[0])
+    inv = np.argsort(perm)                     # theta[perm][inv] == theta
+    big = HPF_Gamma(np.ascontiguousarray(ops["theta_shape"][perm]), np.ascontiguousarray(ops["theta_rate"][perm]))
+    got_ix = hip.compute_Xphi_data_numpy(X, big, beta, theta_ix=inv)
+    assert_allclose(got_ix, ops["xphi_numpy"], rtol=_rt(dt), atol=0)
+
+
 def test_shape_updates_golden(hip, ops):
     dt = ops["xphi_in"].dtype
     N, G = (int(v) for v in ops["shape"])
