@@ -64,15 +64,42 @@ def planted_block(ncells, ngenes, K, target_events, seed):
     beta = rng.gamma(0.3, 1.0, (ngenes, K)) * rng.gamma(2.0, 0.5, (ngenes, 1))
     st, sb = theta.sum(0), beta.sum(0)
     scale = target_events / float((st * sb).sum())
-    rows, cols = [], []
-    for k in range(K):
-        n_k = rng.poisson(st[k] * sb[k] * scale)
-        rows.append(np.searchsorted(np.cumsum(theta[:, k]) / st[k], rng.random_sample(n_k)).astype(np.int32))
-        cols.append(np.searchsorted(np.cumsum(beta[:, k]) / sb[k], rng.random_sample(n_k)).astype(np.int32))
+    # one independent stream per factor so that the factors can be drawn by a thread pool (NumPy
+    # releases the GIL in random_sample / searchsorted) and the matrix does not depend on the pool
+    counts_k = rng.poisson(st * sb * scale)
+    seeds = rng.randint(0, 2 ** 31 - 1, K)
+
+    def draw(k):
+        r = np.random.RandomState(seeds[k])
+        n_k = int(counts_k[k])
+        rr = np.searchsorted(np.cumsum(theta[:, k]) / st[k], r.random_sample(n_k)).astype(np.int32)
+        cc = np.searchsorted(np.cumsum(beta[:, k]) / sb[k], r.random_sample(n_k)).astype(np.int32)
+        return rr, cc
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(K, (os.cpu_count() or 1)))) as pool:
+        drawn = list(pool.map(draw, range(K)))
+    rows = [d[0] for d in drawn]
+    cols = [d[1] for d in drawn]
+    del drawn
     row = np.minimum(np.concatenate(rows), ncells - 1)
     col = np.minimum(np.concatenate(cols), ngenes - 1)
-    X = coo_matrix((np.ones(row.shape[0], np.int32), (row, col)), shape=(ncells, ngenes), dtype=np.int32)
-    X.sum_duplicates()
+    # events -> counts: sort (row, col) keys and count runs (what coo_matrix.sum_duplicates does
+    # through a lexsort, several times slower at 1.6e8 events); the result is canonical row-major
+    bits = max(1, int(ngenes - 1).bit_length())
+    key = (row.astype(np.int64) << bits) | col
+    del row, col
+    key.sort()
+    first = np.empty(key.shape[0], dtype=bool)
+    first[:1] = True
+    np.not_equal(key[1:], key[:-1], out=first[1:])
+    idx = np.flatnonzero(first)
+    del first
+    counts = np.diff(idx, append=key.shape[0]).astype(np.int32)
+    key = key[idx]
+    X = coo_matrix((counts, ((key >> bits).astype(np.int32), (key & ((1 << bits) - 1)).astype(np.int32))),
+                   shape=(ncells, ngenes), dtype=np.int32)
+    X.has_canonical_format = True
     return X
 
 
@@ -81,7 +108,9 @@ def convergence_run(N, G, K, dtype, density):
     1000 iterations, loss every 10, epsilon 0.001 %; scHPF_.py:234-238, 750-761) on planted data,
     host COO in, fitted model out: upload + plan build + iterations + loss checks + download."""
     from schpf import scHPF
+    t_gen = time.perf_counter()
     X = planted_block(N, G, K, target_events=int(N * G * density * 1.6), seed=42)
+    t_gen = time.perf_counter() - t_gen
     # the number of iterations the stop rule takes depends on the random start: three seeds, each a
     # complete fit from the host matrix; the headline is the median wall-clock
     runs = []
@@ -98,6 +127,11 @@ def convergence_run(N, G, K, dtype, density):
     med = sorted(runs, key=lambda r: r["fit_wall_s"])[1]
     return {"data": "planted Gamma-Poisson, %d x %d, nnz %d (density %.4f), max count %d"
                     % (N, G, X.nnz, X.nnz / float(N) / G, int(X.data.max())),
+            "what": "median over 3 random starts of the wall-clock of scHPF.fit(X) -- host COO in, fitted "
+                    "model out: validation, H2D, plan build, t=0 responsibilities, every iteration and loss "
+                    "check, download -- under the reference's default stop rule (min_iter 30, max_iter "
+                    "1000, check_freq 10, epsilon 0.001 %, scHPF_.py:234-238, 750-761)",
+            "unit": "s", "nnz": int(X.nnz), "data_generation_s": t_gen,
             "fit_wall_s": med["fit_wall_s"], "loss_checks": med["loss_checks"], "iterations": med["iterations"],
             "first_loss": med["first_loss"], "final_loss": med["final_loss"], "runs": runs}
 
@@ -122,41 +156,114 @@ def init_engine(eng, X, K, dtype, seed=0):
     return bp, dp, (xi, eta, theta, beta)
 
 
-def cpu_baseline(X, K, dtype, budget_s=20.0):
-    """The CPU oracle (oracle/cavi_oracle.c: the reference's numba execution shape --
-    thread-parallel Xphi + llh, SERIAL scatter-adds, hpf_numba.py:24,54 vs :128,159) timed
-    on a bounded row-subsample of the same matrix, scaled to whole-matrix iterations/s."""
+def _oracle_state(orc, X, K, dtype):
+    np.random.seed(0)
+    bp, dp, st = orc.setup_state(X, K, np.dtype(dtype), 0.3, 1.0, 0.3, 1.0)
+    st.xi_shape[:] = 1.0 + K * 0.3
+    st.eta_shape[:] = 1.0 + K * 0.3
+    return bp, dp, st
+
+
+def _time_iterations(fn, budget_s, max_iters):
+    fn()                                            # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        fn()
+        iters += 1
+        if time.perf_counter() - t0 > budget_s or iters >= max_iters:
+            break
+    return (time.perf_counter() - t0) / iters, iters
+
+
+def cpu_baseline(X, K, dtype):
+    """Both CPU comparators of SURVEY.md 8(d), timed on this box's host cores.
+
+    (i)  "numba-structure" (oracle/cavi_oracle_impl.h): the reference's execution shape --
+         thread-parallel Xphi (nnz x K materialised, K exp per nonzero) and llh, SERIAL
+         scatter-adds and rate updates (hpf_numba.py:24,54 parallel; :128,159 serial).  This is
+         the stand-in for "the reference numba CPU path" (numba itself is not installable here) and
+         is what `value` reports.  It needs 16 GB and minutes per iteration at C3, so it is timed
+         on TWO bounded row-subsamples (about 1/16 and 1/8 of the nonzeros); time is fitted as
+         alpha * nnz + gamma and extrapolated to the whole matrix; the two plain nnz-scalings are
+         reported beside it as the spread.
+    (ii) "fused OpenMP" (oracle/cavi_fused_impl.h): exp hoisted, no Xphi, parallel CSR + CSC
+         passes, AVX2 -- the best CPU form this build knows, on the WHOLE matrix, so that the
+         GPU/CPU ratio is not flattered by the reference's serial scatter."""
     from oracle import hpf_oracle as orc
     orc.build()
     cores = os.cpu_count() or 1
     N, G = X.shape
     nnz_full = X.nnz
-    # ~2e9 nnz*K element-ops per ~10 s of this code on one socket: keep nnz*K <= 2.5e8
-    target_nnz = min(nnz_full, int(2.5e8 / K))
-    rows = max(1, int(N * target_nnz / max(nnz_full, 1)))
-    keep = X.row < rows
-    Xs = coo_matrix((X.data[keep], (X.row[keep], X.col[keep])), shape=(rows, G))
-    np.random.seed(0)
-    bp, dp, st = orc.setup_state(Xs, K, np.dtype(dtype), 0.3, 1.0, 0.3, 1.0)
-    st.xi_shape[:] = 1.0 + K * 0.3
-    st.eta_shape[:] = 1.0 + K * 0.3
-    x, row, col = Xs.data, Xs.row, Xs.col
-    orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=cores)   # warm-up
-    t0 = time.perf_counter()
-    iters = 0
-    while True:
-        orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=cores)
-        iters += 1
-        if time.perf_counter() - t0 > budget_s or iters >= 5:
+    points = []
+    for frac_target in (1.25e8, 2.5e8):            # nnz*K element budget of a sample
+        target_nnz = min(nnz_full, int(frac_target / K))
+        rows = max(1, int(N * target_nnz / max(nnz_full, 1)))
+        keep = X.row < rows
+        Xs = coo_matrix((X.data[keep], (X.row[keep], X.col[keep])), shape=(rows, G))
+        bp, dp, st = _oracle_state(orc, Xs, K, dtype)
+        x, row, col = Xs.data, Xs.row, Xs.col
+        dt, iters = _time_iterations(
+            lambda: orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=cores), 6.0, 4)
+        points.append({"cells": rows, "nnz": int(Xs.nnz), "s_per_iter": dt, "iterations": iters,
+                       "scaled_by_nnz_it_per_s": (1.0 / dt) * Xs.nnz / float(nnz_full)})
+        if Xs.nnz == nnz_full:
             break
-    dt = (time.perf_counter() - t0) / iters
-    scale = Xs.nnz / float(nnz_full)
+    if len(points) == 2 and points[1]["nnz"] > points[0]["nnz"]:
+        alpha = (points[1]["s_per_iter"] - points[0]["s_per_iter"]) / float(points[1]["nnz"] - points[0]["nnz"])
+        gamma = points[1]["s_per_iter"] - alpha * points[1]["nnz"]
+        if alpha <= 0:                              # timing noise: fall back to plain scaling
+            alpha, gamma = points[1]["s_per_iter"] / points[1]["nnz"], 0.0
+        full_s = alpha * nnz_full + max(gamma, 0.0)
+    else:
+        full_s = points[-1]["s_per_iter"] * nnz_full / float(points[-1]["nnz"])
+    value = 1.0 / full_s
+    scaled = [p["scaled_by_nnz_it_per_s"] for p in points]
+    spread = (max(scaled + [value]) - min(scaled + [value])) / value
+
+    # (ii) fused OpenMP on the whole matrix
+    M = orc.FusedMatrix(X, dtype)
+    bp, dp, st = _oracle_state(orc, X, K, dtype)
+    dt_f, it_f = _time_iterations(lambda: orc.fused_iteration(M, st, 0.3, 0.3, bp, dp, nthreads=cores), 8.0, 10)
     return {
-        "value": (1.0 / dt) * scale, "unit": "iterations/s", "cores": cores, "kind": "port",
-        "sample": "first %d of %d cells (nnz %d of %d), %d timed iterations of the reference-"
-                  "structure C oracle (parallel Xphi, serial scatter-adds), %.3f s/iter on the "
-                  "sample, scaled by nnz to the full matrix" % (rows, N, Xs.nnz, nnz_full, iters, dt),
+        "value": value, "unit": "iterations/s", "cores": cores, "kind": "port",
+        "sample": "variant (i) numba-structure C oracle (parallel Xphi + serial scatter-adds, the "
+                  "reference's execution shape), %d threads, timed on the first %d and %d of %d cells "
+                  "(nnz %d and %d of %d; %.3f and %.3f s/iter), extrapolated by a linear fit in nnz to "
+                  "%.2f s/iter for the whole matrix; plain nnz-scaling of the two samples gives %.4f and "
+                  "%.4f it/s (spread %.0f %% of the value)"
+                  % (cores, points[0]["cells"], points[-1]["cells"], N, points[0]["nnz"], points[-1]["nnz"],
+                     nnz_full, points[0]["s_per_iter"], points[-1]["s_per_iter"], full_s, scaled[0],
+                     scaled[-1], 100 * spread),
+        "extrapolation_spread": spread, "sample_points": points,
+        "fused_openmp": {
+            "value": 1.0 / dt_f, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": "variant (ii) fused OpenMP restatement (exp hoisted, no Xphi, parallel CSR + CSC "
+                      "passes, AVX2), %d threads, WHOLE matrix (nnz %d), %d timed iterations, %.3f s/iter"
+                      % (cores, nnz_full, it_f, dt_f),
+        },
+        "note": "CPU baseline = this build's restatements of the reference's path; numba itself cannot be "
+                "installed here (SURVEY.md 8c)",
     }
+
+
+def static_traffic(config, dtype, info):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (PMC needs its own
+    profiler runs, so this is a STATIC figure): attached only when the plan of this run is the
+    plan the counters were collected on (same entry slots and partial rows), with the commit."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh).get("%s/%s" % (config, dtype))
+    except (OSError, ValueError):
+        return None, None
+    if not rec:
+        return None, None
+    sig = rec.get("plan", {})
+    if any(info.get(k) != v for k, v in sig.items()):
+        return None, "profiles/pmc_traffic.json has counters for another plan of %s/%s (stale): not attached" % (config, dtype)
+    return rec["bytes_per_launch"] / 1e9, ("static: (2*FETCH_SIZE + WRITE_SIZE) per launch in GB from %s, "
+                                           "collected at commit %s on this plan" % (rec.get("source"), rec.get("commit")))
 
 
 def main():
@@ -169,8 +276,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded driver (process group, exchange all-reduce) even with one rank")
-    ap.add_argument("--converge", action="store_true",
-                    help="also time a whole fit() to convergence on planted data (N=1 only, adds minutes)")
+    ap.add_argument("--no-converge", action="store_true",
+                    help="skip the wall-clock-to-convergence fits (second half of BASELINE.json's metric)")
     args = ap.parse_args()
 
     import torch
@@ -259,17 +366,7 @@ def main():
     b_launch = b_iter / per_iter
     achieved = b_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     info = eng.plan_info()
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (collected separately, as PMC
-    # must be; profiles/r01/pmc_traffic.json), only for the configuration they were taken on
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-            rec = json.load(fh).get("%s/%s" % (args.config, args.dtype))
-        if rec and world == 1:
-            traffic = rec["bytes_per_launch"] / 1e9
-            traffic_src = "profiles/r01/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE) per launch, GB"
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic, traffic_src = static_traffic(args.config, args.dtype, info) if world == 1 else (None, None)
 
     out = {
         "metric": "CAVI iterations/sec, 100kx20k K=20" if args.config == "c3"
@@ -305,11 +402,20 @@ def main():
         "iterations_per_s_with_loss_every_10": 10.0 / (10 * ms_per_step * 1e-3 + loss_ms * 1e-3),
         "upload_and_plan_s": upload_s,
     }
-    if rank == 0 and world == 1 and args.converge:
+    if rank == 0 and world == 1 and not args.no_converge:
         eng.close()
         out["convergence"] = convergence_run(N, G, K, dtype, density)
+        out["metric"] += " + wall-clock to convergence (see 'convergence')"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(X, K, dtype)
+        if "convergence" in out:     # the same fit at the CPU rates (iterations only, scaled by nnz)
+            scale = out["convergence"]["nnz"] / float(nnz_total)
+            its = out["convergence"]["iterations"]
+            out["convergence"]["cpu_estimate_s"] = {
+                "numba_structure": its * scale / out["cpu_baseline"]["value"],
+                "fused_openmp": its * scale / out["cpu_baseline"]["fused_openmp"]["value"],
+                "how": "iterations of the median GPU fit x (nnz of the planted matrix / nnz of the "
+                       "throughput matrix) / CPU iterations per second; loss checks and set-up not counted"}
     elif rank == 0:
         out["cpu_baseline"] = None
     eng.close()

@@ -35,7 +35,8 @@ def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                              for f in ("cavi_oracle.c", "cavi_oracle_impl.h"))):
+                                              for f in ("cavi_oracle.c", "cavi_oracle_impl.h",
+                                                        "cavi_fused.c", "cavi_fused_impl.h"))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
     return _LIB_PATH
 
@@ -218,6 +219,41 @@ def cavi_iteration(x, row, col, st, a, c, bp, dp, xphi=None, freeze_genes=False,
         _p(st.xi_shape), _p(st.xi_rate), _p(st.theta_shape), _p(st.theta_rate),
         _p(st.eta_shape), _p(st.eta_rate), _p(st.beta_shape), _p(st.beta_rate),
         _p(ws), given, int(bool(freeze_genes)), int(bool(simultaneous)), int(nthreads))
+    return st
+
+
+class FusedMatrix(object):
+    """CSR + CSC copies of X for the fused CPU comparator (built once, like the GPU's plans)."""
+
+    def __init__(self, X, dtype):
+        csr = X.tocsr()
+        csc = X.tocsc()
+        self.shape = X.shape
+        self.dtype = np.dtype(dtype)
+        self.rptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+        self.rcol = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        self.rval = np.ascontiguousarray(csr.data, dtype=dtype)
+        self.cptr = np.ascontiguousarray(csc.indptr, dtype=np.int64)
+        self.crow = np.ascontiguousarray(csc.indices, dtype=np.int32)
+        self.cval = np.ascontiguousarray(csc.data, dtype=dtype)
+
+
+def fused_iteration(M, st, a, c, bp, dp, nthreads=1):
+    """SURVEY.md 8(d) CPU variant (ii), "fused OpenMP": one default-order iteration
+    (scHPF_.py:697-714) with exp hoisted, no Xphi, a parallel CSR pass and a parallel CSC pass
+    (oracle/cavi_fused_impl.h).  In place on `st`; M is a FusedMatrix."""
+    dt = st.theta_shape.dtype
+    assert dt == M.dtype
+    N, K = st.theta_shape.shape
+    G = st.beta_shape.shape[0]
+    assert K <= 256 and (N, G) == tuple(M.shape)
+    for arr in st.arrays():
+        assert arr.dtype == dt and arr.flags.c_contiguous
+    getattr(lib(), "orc_fused_iteration" + _suffix(dt))(
+        N, G, K, _p(M.rptr), _p(M.rcol), _p(M.rval), _p(M.cptr), _p(M.crow), _p(M.cval),
+        ctypes.c_double(a), ctypes.c_double(c), ctypes.c_double(bp), ctypes.c_double(dp),
+        _p(st.xi_shape), _p(st.xi_rate), _p(st.theta_shape), _p(st.theta_rate),
+        _p(st.eta_shape), _p(st.eta_rate), _p(st.beta_shape), _p(st.beta_rate), int(nthreads))
     return st
 
 

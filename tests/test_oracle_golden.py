@@ -122,3 +122,25 @@ def test_project_trace(oracle):
     assert_allclose(st.theta_rate, g["theta_rate"], rtol=1e-8)
     assert_allclose(st.xi_rate, g["xi_rate"], rtol=1e-8)
     assert np.array_equal(st.beta_shape, g["beta_shape"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_cpu_variant_matches_reference_structure(oracle, dtype):
+    """bench.py's second CPU comparator (SURVEY 8(d) variant ii, oracle/cavi_fused_impl.h: exp
+    hoisted, no Xphi, parallel CSR + CSC passes) computes the same iteration as the
+    reference-structure oracle (variant i) -- so both CPU numbers time the same mathematics."""
+    from conftest import synthetic_counts
+    X = synthetic_counts(400, 600, 0.08, seed=5)
+    K, a, c = 12, 0.3, 0.3
+    np.random.seed(3)
+    bp, dp, st = oracle.setup_state(X, K, np.dtype(dtype), a, 1.0, c, 1.0)
+    st.xi_shape[:] = 1.0 + K * a
+    st.eta_shape[:] = 1.0 + K * c
+    fused = st.copy()
+    M = oracle.FusedMatrix(X, dtype)
+    for it in range(3):
+        oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+        oracle.fused_iteration(M, fused, a, c, bp, dp, nthreads=4)
+        rtol = 1e-11 if np.dtype(dtype) == np.float64 else 5e-5 * (it + 1)
+        for got, want in zip(fused.arrays(), st.arrays()):
+            assert_allclose(got, want, rtol=rtol)
