@@ -276,6 +276,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded driver (process group, exchange all-reduce) even with one rank")
+    ap.add_argument("--graph", action="store_true",
+                    help="time the steps as ONE schpf_steps call (a hipGraph replay, what scHPF.fit issues "
+                         "between two loss checks); the kernel times for the roofline then come from a "
+                         "second, eager pass.  Default for the launch-bound config c2.")
+    ap.add_argument("--comm", default="library", choices=["library", "torch"],
+                    help="sharded runs: all-reduce issued by the library (RCCL bound at run time, one call per "
+                         "stretch of iterations) or by torch.distributed from Python (ShardedCAVI)")
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the wall-clock-to-convergence fits (second half of BASELINE.json's metric)")
     args = ap.parse_args()
@@ -313,7 +320,19 @@ def main():
     init_engine(eng, X, K, dtype)
     upload_s = time.perf_counter() - t_up
     nnz_local = X.nnz
-    if sharded:
+    use_graph = (args.graph or args.config == "c2") and not sharded
+    if sharded and args.comm == "library":
+        from schpf_amd.sharded import NativeShard
+        # rank 0's communicator id reaches the other ranks through the process group that is there anyway
+        uid = [DeviceCAVI.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        drv = NativeShard(eng, uid[0], rank, world)
+        step = drv.step
+        nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nnz_t)
+        nnz_total = int(nnz_t.item())
+        loss_fn = drv.mean_negative_pois_llh
+    elif sharded:
         drv = ShardedCAVI(eng, exchange_tensor_of(eng, local_rank))
         step = drv.step
         nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
@@ -333,17 +352,32 @@ def main():
     eng.init_phi_device(12345)          # t = 0 responsibilities (device generator)
     for _ in range(args.warmup):
         step()
+    if use_graph:
+        eng.steps(args.steps)           # untimed: captures the K-iteration graph the timed call replays
     loss_start = loss_fn()
-    eng.profile(True)
-    eng.profile_read()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile(False)
+    if use_graph:
+        fence()
+        t0 = time.perf_counter()
+        eng.steps(args.steps)           # EXACTLY K iterations, one hipGraph launch
+        fence()
+        elapsed = time.perf_counter() - t0
+        eng.profile(True)               # kernel times for the roofline: a second, eager pass of K iterations
+        eng.profile_read()
+        for _ in range(args.steps):
+            step()
+        prof = eng.profile_read()
+        eng.profile(False)
+    else:
+        eng.profile(True)
+        eng.profile_read()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile(False)
     if sharded:
         el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -379,8 +413,11 @@ def main():
                         "RandomState(42+1000*rank) per row block), nnz %d after summing duplicates, "
                         "K=%d, one CAVI iteration per step (no loss evaluation inside the step)"
                         % (args.config.upper(), N, G, density, nnz_total, K),
-            "parallelism": "cells row-sharded x%d, one RCCL all-reduce of G*K+K per iteration" % world
+            "parallelism": ("cells row-sharded x%d, one RCCL all-reduce of G*K+K per iteration (%s)"
+                            % (world, "issued by the library" if args.comm == "library" else "torch.distributed"))
                            if world > 1 else "single GPU",
+            "launch": "one hipGraph of %d iterations (schpf_steps), +%d untimed iterations to capture it"
+                      % (args.steps, args.steps) if use_graph else "one library call per iteration, eager launches",
             "plan": info,
         },
         "roofline": {

@@ -148,6 +148,11 @@ int schpf_init_phi_device(schpf_ctx *ctx, uint64_t seed);
  * xi.rate].  schpf_step = schpf_step_local + schpf_step_finish on one GPU. */
 int schpf_step(schpf_ctx *ctx, unsigned flags);
 
+/* n iterations in one call -- the iterations between two loss checks of scHPF._fit
+ * (scHPF_.py:642-718 with check_freq).  Same result as n schpf_step calls; from the second call
+ * with the same (flags, n) the iterations are replayed as one hipGraph (SCHPF_GRAPH=0 disables). */
+int schpf_steps(schpf_ctx *ctx, unsigned flags, int n);
+
 /* Sharded form: _local runs both sweeps and packs the gene-side sums [G*K] followed by
  * the local sum_i E[theta_ik] [K] into the exchange buffer (device memory, dtype T);
  * the host all-reduces (sum) that buffer over the ranks (RCCL), then calls _finish. */
@@ -162,6 +167,21 @@ int schpf_loss_terms(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64
 
 int schpf_synchronize(schpf_ctx *ctx);
 
+/* Cells sharded over the GPUs of a node, the collective inside the library (RCCL over xGMI, bound
+ * at run time to the copy of librccl.so already in the process -- PyTorch's when torch is loaded
+ * -- else $SCHPF_RCCL_PATH, else /opt/rocm/lib).  One context per GPU (per process, or per host
+ * thread of one process).  schpf_comm_unique_id: 128 bytes from ONE rank, handed to all others by
+ * the host (a file, MPI, torch.distributed, a Python list between threads); schpf_comm_init: every
+ * rank, collectively (it blocks until all `world` ranks have called it).  schpf_steps_sharded =
+ * n x [schpf_step_local(gene side) -> all-reduce of the exchange buffer on the communicator's own
+ * stream, under the cell-side sweep -> schpf_step_finish]; freeze_genes needs no exchange.
+ * schpf_loss_terms_all = schpf_loss_terms summed over the ranks. */
+int schpf_comm_unique_id(void *out128);
+int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int world);
+int schpf_comm_destroy(schpf_ctx *ctx);
+int schpf_steps_sharded(schpf_ctx *ctx, unsigned flags, int n);
+int schpf_loss_terms_all(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64_t *nnz);
+
 /* The hipStream_t the context enqueues on (0 = the null stream), so that a caller can order its
  * own work -- the all-reduce of the exchange buffer -- with the engine's kernels. */
 int schpf_stream_handle(schpf_ctx *ctx, void **stream);
@@ -174,9 +194,11 @@ int schpf_stream_handle(schpf_ctx *ctx, void **stream);
 int schpf_profile_enable(schpf_ctx *ctx, int enable);
 int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
 
-/* Plan facts for reports: info[0..] = KP, KL, LPC, chunk_len, windows_cell, windows_gene,
- * n_chunks_cell, n_chunks_gene, n_waves_cell, n_waves_gene, stored entry slots cell, gene */
-int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]);
+/* Plan facts for reports: info[0..] = KP, KL, LPC, chunk_len (tile plan: minus the rows per LDS
+ * window / ring slot), windows_cell, windows_gene, n_chunks_cell, n_chunks_gene, n_waves_cell,
+ * n_waves_gene, stored entry slots cell, gene, ring slots cell, gene (1 = window schedule),
+ * bytes per ring slot, waves per workgroup */
+int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]);
 
 /* Facts about the uploaded matrix: info = {nnz, values that were rounded to float32, explicitly
  * stored zeros, 1 if the packed 8-byte entry format is in use}. */
@@ -201,12 +223,15 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
 
 /* Same for the tile plan (LDS-staged sweep): per stored nonzero the major/minor/val, the partial
  * row (task * groups_per_block + group) it accumulates into and its task; pfirst/pcount[n_major];
- * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task}. */
+ * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task}.
+ * ring <= 1: window schedule with win_rows rows per window; ring >= 3: ring schedule with `ring`
+ * slots of slot_bytes (a multiple of 1024 * waves_per_block; table rows are 160 bytes here) -- the
+ * hook then also checks that every entry of an epoch points into a slot readable in that epoch. */
 int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                             int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                            int target_tasks, int32_t *out_major, int32_t *out_minor, float *out_val,
-                            int32_t *out_prow, int32_t *out_task, int32_t *out_pfirst,
-                            int32_t *out_pcount, int64_t stats[6]);
+                            int target_tasks, int ring, int slot_bytes, int32_t *out_major,
+                            int32_t *out_minor, float *out_val, int32_t *out_prow, int32_t *out_task,
+                            int32_t *out_pfirst, int32_t *out_pcount, int64_t stats[6]);
 
 #ifdef __cplusplus
 }

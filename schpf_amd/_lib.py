@@ -43,11 +43,17 @@ SIGNATURES = {
     "schpf_init_phi_host": [_vp, _vp],
     "schpf_init_phi_device": [_vp, ctypes.c_uint64],
     "schpf_step": [_vp, ctypes.c_uint],
+    "schpf_steps": [_vp, ctypes.c_uint, _int],
     "schpf_step_local": [_vp, ctypes.c_uint],
     "schpf_exchange_buffer": [_vp, ctypes.POINTER(_vp), _i64p],
     "schpf_step_finish": [_vp, ctypes.c_uint],
     "schpf_loss_terms": [_vp, _dblp, _dblp, _i64p],
     "schpf_synchronize": [_vp],
+    "schpf_comm_unique_id": [_vp],
+    "schpf_comm_init": [_vp, _vp, _int, _int],
+    "schpf_comm_destroy": [_vp],
+    "schpf_steps_sharded": [_vp, ctypes.c_uint, _int],
+    "schpf_loss_terms_all": [_vp, _dblp, _dblp, _i64p],
     "schpf_stream_handle": [_vp, ctypes.POINTER(_vp)],
     "schpf_profile_enable": [_vp, _int],
     "schpf_profile_read": [_vp, _dblp, _i64p],
@@ -56,7 +62,7 @@ SIGNATURES = {
     "schpf_coo_marginals": [_i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp],
     "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64p],
-    "schpf_debug_tile_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int,
+    "schpf_debug_tile_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64p],
 }
 STRING_FUNCS = ("schpf_last_error", "schpf_version")
@@ -117,6 +123,11 @@ def load():
             "libschpf_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
     HIP_RUNTIME = _hip_runtime_path()
+    # RCCL follows the HIP runtime: the copy next to it (torch/lib or /opt/rocm/lib) unless overridden
+    if not os.environ.get("SCHPF_RCCL_PATH"):
+        cand = os.path.join(os.path.dirname(HIP_RUNTIME), "librccl.so")
+        if os.path.exists(cand):
+            os.environ["SCHPF_RCCL_PATH"] = cand
     try:
         ctypes.CDLL(HIP_RUNTIME, mode=ctypes.RTLD_GLOBAL)
     except OSError as e:

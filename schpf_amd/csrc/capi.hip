@@ -2,6 +2,8 @@
 // ordering of kernel launches that makes one CAVI iteration (scHPF_.py:657-714).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -152,6 +154,55 @@ struct ScopedTimer {
     }
 };
 
+// ---- RCCL, bound at run time.  The library has no DT_NEEDED on RCCL for the reason it has none on
+// the HIP runtime (Makefile): a process must use ONE copy, and PyTorch bundles its own.  The copy
+// already in the process is taken when there is one (RTLD_NOLOAD), else $SCHPF_RCCL_PATH, else
+// the system's.  Only the handful of entry points the sharded iteration needs; the types are the
+// C ABI of rccl.h (ncclUniqueId = 128 opaque bytes, ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0).
+struct RcclUniqueId { char internal[128]; };
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) {
+        if (!r.handle) throw std::runtime_error("RCCL is not available in this process");
+        return r;
+    }
+    tried = true;
+    const char *env = getenv("SCHPF_RCCL_PATH");
+    const char *names[] = {"librccl.so", "librccl.so.1", env && *env ? env : nullptr, "librccl.so", "librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
+    for (int i = 0; i < 6 && !r.handle; ++i) {
+        if (!names[i]) continue;
+        r.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL | (i < 2 ? RTLD_NOLOAD : 0));
+    }
+    if (!r.handle) throw std::runtime_error("cannot load RCCL (librccl.so): set SCHPF_RCCL_PATH");
+    auto sym = [&](const char *n) {
+        void *p = dlsym(r.handle, n);
+        if (!p) { r.handle = nullptr; throw std::runtime_error(std::string("RCCL lacks ") + n); }
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+}
+#define RCCLCHK(expr)                                                                                     \
+    do {                                                                                                  \
+        const int r_ = (expr);                                                                            \
+        if (r_ != 0) throw std::runtime_error(std::string(#expr " failed: ") + rccl().GetErrorString(r_)); \
+    } while (0)
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -160,7 +211,7 @@ struct schpf_ctx {
     int KP = 0, KL = 0, LPC = 1, NV = 1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    virtual ~schpf_ctx() {}
+    virtual ~schpf_ctx() { comm_destroy(); }
     virtual void upload_coo(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind) = 0;
     virtual void set_state(int which, const void *shape, const void *rate) = 0;
     virtual void get_state(int which, void *shape, void *rate) = 0;
@@ -168,9 +219,37 @@ struct schpf_ctx {
     virtual void init_phi_device(uint64_t seed) = 0;
     virtual void step_local(unsigned flags) = 0;
     virtual void step_finish(unsigned flags) = 0;
+    virtual void steps(unsigned flags, int n) = 0;
+    virtual void hypers_changed() = 0;
+    virtual void steps_sharded(unsigned flags, int n) = 0;
+    virtual void loss_terms_all(double *llh, double *gl, int64_t *nnz) = 0;
+    // cells sharded over GPUs: this rank's RCCL communicator and the stream its collectives run on
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_reduced = nullptr;
+    void comm_init(const void *id, int rank, int world)
+    {
+        if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("rank must be in [0, world)");
+        comm_destroy();
+        RcclUniqueId uid;
+        std::memcpy(&uid, id, sizeof uid);
+        RCCLCHK(rccl().CommInitRank(&comm, world, uid, rank));
+        comm_rank = rank; comm_world = world;
+        HIPCHK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_reduced, hipEventDisableTiming));
+    }
+    void comm_destroy()
+    {
+        if (comm) { (void)hipStreamSynchronize(comm_stream); (void)rccl().CommDestroy(comm); comm = nullptr; }
+        if (comm_stream) { (void)hipStreamDestroy(comm_stream); comm_stream = nullptr; }
+        if (ev_packed) { (void)hipEventDestroy(ev_packed); ev_packed = nullptr; }
+        if (ev_reduced) { (void)hipEventDestroy(ev_reduced); ev_reduced = nullptr; }
+    }
     virtual void exchange(void **p, int64_t *count) = 0;
     virtual void loss_terms(double *llh, double *gl, int64_t *nnz) = 0;
-    virtual void plan_info(int64_t info[12]) = 0;
+    virtual void plan_info(int64_t info[16]) = 0;
     virtual void upload_info(int64_t info[4]) = 0;
     double a = 0.3, c = 0.3, bp = 1.0, dp = 1.0;
     Profiler prof;
@@ -200,7 +279,14 @@ template <typename T> struct Engine final : schpf_ctx {
     bool have_coo = false;
     bool dirty_theta = true, dirty_beta = true;
     int pending_init = 0;  // 0 none, 1 dense accumulators, 2 chunk partials
+    // n iterations captured as one hipGraph (schpf_steps): the state is device-resident and nothing on
+    // the host changes between two loss checks, so a fit replays one graph per check interval
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned graph_flags = 0;
+    int graph_n = 0;
+    bool eager_since_upload = false;   // one eager iteration has run on this plan (kernel attributes are set)
     static constexpr int UPD_BLOCKS = 2048;
+    static constexpr size_t TABLE_PAD = 256 * 1024;
 
     Engine(int device_, void *stream_, int dtype_, int N_, int G_, int K_)
     {
@@ -217,16 +303,104 @@ template <typename T> struct Engine final : schpf_ctx {
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
         be_s.alloc((size_t)G * K * s); be_r.alloc((size_t)G * K * s);
-        for (DevBuf *b : {&th_exp, &th_e, &th_log}) b->alloc((size_t)N * KP * s, true, stream);
-        for (DevBuf *b : {&be_exp, &be_e, &be_log}) b->alloc((size_t)G * KP * s, true, stream);
+        // + TABLE_PAD zero bytes: the ring sweep copies whole 1 KiB pieces and may read past the last row
+        for (DevBuf *b : {&th_exp, &th_e, &th_log}) b->alloc((size_t)N * KP * s + TABLE_PAD, true, stream);
+        for (DevBuf *b : {&be_exp, &be_e, &be_log}) b->alloc((size_t)G * KP * s + TABLE_PAD, true, stream);
         exchange_buf.alloc(((size_t)G * K + K) * s, true, stream);
         for (DevBuf *b : {&s_theta, &s_beta, &s_beta_next}) b->alloc((size_t)K * sizeof(double), true, stream);
         colpart_cell.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
         colpart_gene.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
         scalars.alloc(8 * sizeof(double), true, stream);
     }
+    void hypers_changed() override { drop_graph(); }   // a, c, bp, dp are kernel arguments of the captured launches
+    void drop_graph()
+    {
+        if (graph_exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        graph_n = 0;
+    }
+
+    // n iterations of schpf_step.  From the second call on with the same (flags, n) they are one
+    // graph launch: launch overhead is what bounds small matrices (BASELINE C2: five launches of
+    // 5-25 us each per iteration).  The sum-of-beta buffers swap roles every iteration, so a graph
+    // always holds an even number of iterations; an odd one runs eagerly.
+    void steps(unsigned flags_, int n) override
+    {
+        if (n < 0) throw std::invalid_argument("n must be >= 0");
+        const bool graphable = env_int("SCHPF_GRAPH", 1) && !prof.on && stream != nullptr && pending_init == 0 &&
+                               eager_since_upload && !dirty_theta && !dirty_beta && !(flags_ & SCHPF_SHARDED);
+        int done = 0;
+        if (graphable && n >= 2) {
+            const int even = n & ~1;
+            if (!graph_exec || graph_flags != flags_ || graph_n != even) {
+                drop_graph();
+                hipGraph_t graph = nullptr;
+                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    for (int i = 0; i < even; ++i) { step_local(flags_); step_finish(flags_); }
+                } catch (...) {
+                    (void)hipStreamEndCapture(stream, &graph);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    throw;
+                }
+                HIPCHK(hipStreamEndCapture(stream, &graph));
+                const hipError_t e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                HIPCHK(e);
+                graph_flags = flags_;
+                graph_n = even;
+                // the capture ran the host side of `even` iterations (pointer swaps) without executing them
+            }
+            HIPCHK(hipGraphLaunch(graph_exec, stream));
+            done = even;
+        }
+        for (; done < n; ++done) { step_local(flags_); step_finish(flags_); }
+        if (n > 0) eager_since_upload = true;
+    }
+
+    // n iterations with the cells sharded over the ranks of `comm` (sharded.py protocol, driven from
+    // here): gene-side sweep + packing on the context's stream; ONE all-reduce of [G*K sums | K sums
+    // of E[theta]] on the communicator's stream, ordered after the packing by an event; the
+    // cell-side sweep meanwhile; the update kernels after an event on the all-reduce.  No host
+    // round trip and no Python between the launches of an iteration.
+    void steps_sharded(unsigned flags_, int n) override
+    {
+        if (!comm) throw std::logic_error("no communicator (schpf_comm_init)");
+        const unsigned base = (flags_ | SCHPF_SHARDED) & ~(unsigned)(SCHPF_LOCAL_GENE | SCHPF_LOCAL_CELL);
+        const bool freeze = flags_ & SCHPF_FREEZE_GENES;
+        const int dt = sizeof(T) == 4 ? 7 : 8;   // ncclFloat32 / ncclFloat64
+        for (int i = 0; i < n; ++i) {
+            if (freeze) { step_local(base); step_finish(base); continue; }   // nothing to exchange
+            step_local(base | SCHPF_LOCAL_GENE);
+            HIPCHK(hipEventRecord(ev_packed, stream));
+            HIPCHK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
+            RCCLCHK(rccl().AllReduce(exchange_buf.p, exchange_buf.p, (size_t)G * K + K, dt, 0, comm, comm_stream));
+            HIPCHK(hipEventRecord(ev_reduced, comm_stream));
+            step_local(base | SCHPF_LOCAL_CELL);
+            HIPCHK(hipStreamWaitEvent(stream, ev_reduced, 0));
+            step_finish(base);
+        }
+        if (n > 0) eager_since_upload = true;
+    }
+
+    // loss terms summed over the ranks (three doubles through the same communicator)
+    void loss_terms_all(double *llh, double *gl, int64_t *nnz_out) override
+    {
+        if (!comm) throw std::logic_error("no communicator (schpf_comm_init)");
+        double h[3];
+        int64_t local_nnz = 0;
+        loss_terms(&h[0], &h[1], &local_nnz);
+        h[2] = (double)local_nnz;
+        double *d = scalars.as<double>() + 4;
+        HIPCHK(hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, stream));
+        RCCLCHK(rccl().AllReduce(d, d, 3, 8, 0, comm, stream));
+        HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        *llh = h[0]; *gl = h[1]; *nnz_out = (int64_t)(h[2] + 0.5);
+    }
+
     ~Engine() override
     {
+        drop_graph();
         (void)hipStreamSynchronize(stream);
         if (own_stream) (void)hipStreamDestroy(stream);
     }
@@ -326,7 +500,7 @@ template <typename T> struct Engine final : schpf_ctx {
         const int wpb = h.wpb;
         td.n_tasks = h.n_tasks;
         td.threads = 64 * wpb;
-        td.lds_bytes = (size_t)h.win_rows * KP * sizeof(T);
+        td.lds_bytes = h.ring > 1 ? (size_t)h.ring * h.slot16 * 16 : (size_t)h.win_rows * KP * sizeof(T);
         td.packed = h.packed;
         td.n_wave_out = h.n_tasks * wpb;
         upload(td.block_rows, h.block_rows, stream);
@@ -347,11 +521,7 @@ template <typename T> struct Engine final : schpf_ctx {
     void build_tiles_device(const int32_t *row, const int32_t *col, const float *val, bool packed_ok)
     {
         const double t0 = now_s();
-        int wpb_c, wr_c, tk_c, wpb_g, wr_g, tk_g;
-        tile_shape(N, G, wpb_c, wr_c, tk_c);
-        tile_shape(G, N, wpb_g, wr_g, tk_g);
-        const bool allow_pack = env_int("SCHPF_PACK", 1) != 0;
-        const int row_slots = env_int("SCHPF_BANK_ORDER", 1) ? (int)((size_t)KP * sizeof(T) / 16) : 0;
+        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N);
         bool rc_sorted = true, cr_sorted = true;
         schpf::coo_order_flags(nnz, row, col, rc_sorted, cr_sorted);
         DevBuf d_row, d_col, d_val;
@@ -369,9 +539,8 @@ template <typename T> struct Engine final : schpf_ctx {
             const bool presorted = side == 0 ? rc_sorted : cr_sorted;
             schpf::build_tile_plan_device((void *)stream, nnz, side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>(),
                                           side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>(), d_val.as<float>(),
-                                          presorted, packed_ok, side == 0 ? N : G, side == 0 ? G : N, LPC,
-                                          side == 0 ? wpb_c : wpb_g, side == 0 ? wr_c : wr_g, side == 0 ? tk_c : tk_g,
-                                          allow_pack, row_slots, td.host, &e, &eb, &s, &o);
+                                          presorted, packed_ok, side == 0 ? N : G, side == 0 ? G : N,
+                                          side == 0 ? sh_c : sh_g, td.host, &e, &eb, &s, &o);
             td.entries.release(); td.entries.p = e; td.entries.bytes = eb;
             td.steps.release(); td.steps.p = s; td.steps.bytes = td.host.steps.size() * 2;
             td.order_dev.release(); td.order_dev.p = o; td.order_dev.bytes = o ? (size_t)nnz * 4 : 0;
@@ -391,9 +560,9 @@ template <typename T> struct Engine final : schpf_ctx {
     // two workgroups per CU) until there are.  Measured on a 1/8 shard of C3 and on C2
     // (SCHPF_MIN_PAIRS = 768 / 256 / 128 / 64): the large workgroup wins well below one task per
     // CU, because both orientations share a launch and small windows cost padding and partials.
-    void tile_shape(int n_major, int n_minor, int &wpb, int &win_rows, int &tasks) const
+    schpf::TileShape tile_shape(int n_major, int n_minor) const
     {
-        wpb = env_int("SCHPF_WPB", 0);
+        int wpb = env_int("SCHPF_WPB", 0);
         int lds_kb = env_int("SCHPF_LDS_KB", 0);
         const size_t row_bytes = (size_t)KP * sizeof(T);
         if (!wpb) {
@@ -408,37 +577,67 @@ template <typename T> struct Engine final : schpf_ctx {
             }
         }
         if (!lds_kb) lds_kb = wpb >= 12 ? 152 : 64;
-        win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
+        schpf::TileShape sh;
+        sh.lpc = LPC;
+        sh.waves_per_block = wpb;
+        sh.row_slots = (int)(row_bytes / 16);
+        sh.bank_order = env_int("SCHPF_BANK_ORDER", 1) != 0;
+        sh.allow_packed = env_int("SCHPF_PACK", 1) != 0;
+        sh.win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
+        // Ring schedule (plan.h) when a ring slot still holds several nonzeros per row: slots of 2 KiB per
+        // wave (every wave issues two 1 KiB copies per epoch), as many as fit the workgroup's LDS
+        // (5 x 32 KiB = all 160 KiB of the CU for a 1024-thread workgroup; at most 8).  Sparse x wide problems
+        // (about a nonzero per row and slot) would spend their time at epoch barriers: window mode.
+        // Opt-in (SCHPF_RING >= 3): measured at BASELINE C3 the ring schedule fills 0.80-0.85 of the
+        // step slots against the window schedule's 0.68 and still loses 8 % (f64) / 15 % (f32): a
+        // barrier every ~7 steps instead of every ~30 costs more SIMD occupancy around the barrier than
+        // the padding it saves (profiles/r02/explore_ring_schedule.log).
+        const int ring_env = env_int("SCHPF_RING", 0);
+        if (ring_env > 1 && !schpf::ring_schedule_compiled())
+            throw std::invalid_argument("SCHPF_RING: this build has no ring schedule (it is compiled with "
+                                        "-DSCHPF_WITH_RING, tools/devbuild.sh); unknown to the shipped library");
+        if (ring_env != 0 && ring_env != 1) {
+            const int lds_total = (wpb >= 12 && !env_int("SCHPF_LDS_KB", 0)) ? 160 : lds_kb;
+            const int slot_kb = 2 * wpb;                  // the kernel copies two 1 KiB pieces per wave and epoch
+            int ring = std::min(lds_total / slot_kb, 8);
+            if (ring_env > 1) ring = std::min(ring, ring_env);
+            const int64_t sub_rows = (int64_t)slot_kb * 1024 / (int64_t)row_bytes;
+            const double per_row = (double)nnz / std::max(1, n_major) * (double)sub_rows / std::max(1, n_minor);
+            if (ring >= 3 && sub_rows >= 1 && (int64_t)ring * slot_kb * 64 <= 65536 &&
+                (ring_env > 1 || per_row >= (double)env_int("SCHPF_RING_MIN_NNZ", 6))) {
+                sh.ring = ring;
+                sh.slot_bytes = slot_kb * 1024;
+                sh.win_rows = (int)sub_rows;
+            }
+        }
         // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
         // there are few (block, window) pairs (1/8 shard of C3: 1024 -> 256 tasks is 10 % faster:
         // fewer partial rows to write and to sum, no ragged second round)
+        const int64_t lds_rows = sh.ring > 1 ? (int64_t)sh.win_rows * (sh.ring - 1) : sh.win_rows;
         const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
-        const int64_t windows = ((int64_t)n_minor + win_rows - 1) / win_rows;
-        tasks = env_int("SCHPF_TASKS", blocks * windows >= 2048 ? (wpb >= 12 ? 1024 : 2048) : 256);
+        const int64_t windows = ((int64_t)n_minor + lds_rows - 1) / lds_rows;
+        sh.target_tasks = env_int("SCHPF_TASKS", blocks * windows >= 2048 ? (wpb >= 12 ? 1024 : 2048) : 256);
+        return sh;
     }
 
     // both orientations are built concurrently on the host (each with its own thread team),
     // then uploaded one after the other on the context's stream
     void build_tiles(const int32_t *row, const int32_t *col, const float *val)
     {
-        int wpb_c, wr_c, tk_c, wpb_g, wr_g, tk_g;
-        tile_shape(N, G, wpb_c, wr_c, tk_c);
-        tile_shape(G, N, wpb_g, wr_g, tk_g);
-        const bool allow_pack = env_int("SCHPF_PACK", 1) != 0;
-        const int row_slots = env_int("SCHPF_BANK_ORDER", 1) ? (int)((size_t)KP * sizeof(T) / 16) : 0;
+        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N);
         std::exception_ptr err;
         double secs_gene = 0.0;
         std::thread side([&] {
             try {
                 const double t0 = now_s();
-                schpf::build_tile_plan(nnz, col, row, val, G, N, LPC, wpb_g, wr_g, tk_g, true, allow_pack, row_slots, tgene.host);
+                schpf::build_tile_plan(nnz, col, row, val, G, N, sh_g, true, tgene.host);
                 secs_gene = now_s() - t0;
             } catch (...) { err = std::current_exception(); }
         });
         double secs_cell = 0.0;
         try {
             const double t0 = now_s();
-            schpf::build_tile_plan(nnz, row, col, val, N, G, LPC, wpb_c, wr_c, tk_c, true, allow_pack, row_slots, tcell.host);
+            schpf::build_tile_plan(nnz, row, col, val, N, G, sh_c, true, tcell.host);
             secs_cell = now_s() - t0;
         } catch (...) { side.join(); throw; }
         side.join();
@@ -572,6 +771,8 @@ template <typename T> struct Engine final : schpf_ctx {
         HIPCHK(hipStreamSynchronize(stream));
         have_coo = true;
         pending_init = 0;
+        drop_graph();
+        eager_since_upload = false;
         if (verbose)
             fprintf(stderr, "[schpf_hip] upload_coo nnz=%lld: validate %.3f s, plans+H2D %.3f s, gammaln %.3f s (%d host threads)\n",
                     (long long)nnz, t_valid - t_start, t_plans - t_valid, now_s() - t_plans, schpf::host_threads());
@@ -611,6 +812,7 @@ template <typename T> struct Engine final : schpf_ctx {
         HIPCHK(hipStreamSynchronize(stream));
         if (which == SCHPF_THETA) dirty_theta = true;
         if (which == SCHPF_BETA) dirty_beta = true;
+        // the graph reads the parameters through fixed pointers: still valid; only xi/eta shapes are constants
     }
     void get_state(int which, void *shape, void *rate) override
     {
@@ -696,6 +898,7 @@ template <typename T> struct Engine final : schpf_ctx {
         a.wave_out = wave_out.as<double>();
         a.K = K; a.n_minor = n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
         a.wpb = td.host.wpb;
+        a.ring = td.host.ring; a.slot_bytes = td.host.slot16 * 16;
         return a;
     }
 
@@ -926,9 +1129,11 @@ template <typename T> struct Engine final : schpf_ctx {
         info[3] = use_tile ? (tcell.packed ? 1 : 0) : 0;
     }
 
-    void plan_info(int64_t info[12]) override
+    void plan_info(int64_t info[16]) override
     {
         info[0] = KP; info[1] = KL; info[2] = LPC;
+        info[12] = use_tile ? tcell.host.ring : 0; info[13] = use_tile ? tgene.host.ring : 0;
+        info[14] = use_tile ? tcell.host.slot16 * 16 : 0; info[15] = use_tile ? tcell.host.wpb : 0;
         if (use_tile) {
             info[3] = -tcell.host.win_rows;            // negative: tile plan, rows per LDS window
             info[4] = tcell.host.n_windows; info[5] = tgene.host.n_windows;
@@ -1079,7 +1284,10 @@ bool bad_dtype(int dtype) { return dtype != SCHPF_F32 && dtype != SCHPF_F64; }
 extern "C" {
 
 const char *schpf_last_error(void) { return g_err.c_str(); }
-const char *schpf_version(void) { return "schpf_hip 0.1 (gfx950)"; }
+const char *schpf_version(void)
+{
+    return schpf::ring_schedule_compiled() ? "schpf_hip 0.2 (gfx950) +ring" : "schpf_hip 0.2 (gfx950)";
+}
 
 int schpf_device_count(int *count)
 {
@@ -1175,7 +1383,7 @@ int schpf_upload_coo(schpf_ctx *ctx, int64_t nnz, const int32_t *row, const int3
 int schpf_set_hypers(schpf_ctx *ctx, double a, double c, double bp, double dp)
 {
     if (!(a > 0 && c > 0 && bp > 0 && dp > 0)) return fail("hyperparameters must be positive");
-    CTX_CALL(ctx->a = a; ctx->c = c; ctx->bp = bp; ctx->dp = dp);
+    CTX_CALL(ctx->a = a; ctx->c = c; ctx->bp = bp; ctx->dp = dp; ctx->hypers_changed());
 }
 int schpf_set_state(schpf_ctx *ctx, int which, const void *shape, const void *rate)
 {
@@ -1190,7 +1398,7 @@ int schpf_init_phi_device(schpf_ctx *ctx, uint64_t seed) { CTX_CALL(ctx->init_ph
 int schpf_step(schpf_ctx *ctx, unsigned flags)
 {
     if (flags & SCHPF_SHARDED) return fail("schpf_step is the single-GPU form; use step_local/step_finish");
-    CTX_CALL(ctx->step_local(flags); ctx->step_finish(flags));
+    CTX_CALL(ctx->steps(flags, 1));
 }
 int schpf_step_local(schpf_ctx *ctx, unsigned flags) { CTX_CALL(ctx->step_local(flags)); }
 int schpf_exchange_buffer(schpf_ctx *ctx, void **device_ptr, int64_t *count)
@@ -1198,11 +1406,41 @@ int schpf_exchange_buffer(schpf_ctx *ctx, void **device_ptr, int64_t *count)
     CTX_CALL(ctx->exchange(device_ptr, count));
 }
 int schpf_step_finish(schpf_ctx *ctx, unsigned flags) { CTX_CALL(ctx->step_finish(flags)); }
+int schpf_steps(schpf_ctx *ctx, unsigned flags, int n)
+{
+    if (flags & SCHPF_SHARDED) return fail("schpf_steps is the single-GPU form; use step_local/step_finish");
+    CTX_CALL(ctx->steps(flags, n));
+}
 int schpf_loss_terms(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64_t *nnz)
 {
     CTX_CALL(ctx->loss_terms(llh_sum, gammaln_sum, nnz));
 }
 int schpf_synchronize(schpf_ctx *ctx) { CTX_CALL(HIPCHK(hipStreamSynchronize(ctx->stream))); }
+
+int schpf_comm_unique_id(void *out128)
+{
+    if (!out128) return fail("out is NULL");
+    return guarded([&] {
+        RcclUniqueId id;
+        RCCLCHK(rccl().GetUniqueId(&id));
+        std::memcpy(out128, &id, sizeof id);
+    });
+}
+int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int world)
+{
+    if (!unique_id128) return fail("unique_id is NULL");
+    CTX_CALL(ctx->comm_init(unique_id128, rank, world));
+}
+int schpf_comm_destroy(schpf_ctx *ctx) { CTX_CALL(ctx->comm_destroy()); }
+int schpf_steps_sharded(schpf_ctx *ctx, unsigned flags, int n)
+{
+    if (n < 0) return fail("n must be >= 0");
+    CTX_CALL(ctx->steps_sharded(flags, n));
+}
+int schpf_loss_terms_all(schpf_ctx *ctx, double *llh_sum, double *gammaln_sum, int64_t *nnz)
+{
+    CTX_CALL(ctx->loss_terms_all(llh_sum, gammaln_sum, nnz));
+}
 int schpf_stream_handle(schpf_ctx *ctx, void **stream)
 {
     if (!stream) return fail("stream is NULL");
@@ -1225,7 +1463,7 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
         }
         ctx->prof.recs.clear());
 }
-int schpf_plan_info(schpf_ctx *ctx, int64_t info[12]) { CTX_CALL(ctx->plan_info(info)); }
+int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]) { CTX_CALL(ctx->plan_info(info)); }
 int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]) { CTX_CALL(ctx->upload_info(info)); }
 
 int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind,
@@ -1316,14 +1554,18 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
 
 int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                             int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                            int target_tasks, int32_t *out_major, int32_t *out_minor, float *out_val,
-                            int32_t *out_prow, int32_t *out_task, int32_t *out_pfirst, int32_t *out_pcount,
-                            int64_t stats[6])
+                            int target_tasks, int ring, int slot_bytes, int32_t *out_major, int32_t *out_minor,
+                            float *out_val, int32_t *out_prow, int32_t *out_task, int32_t *out_pfirst,
+                            int32_t *out_pcount, int64_t stats[6])
 {
     return guarded([&] {
         schpf::TilePlanHost P;
-        schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, lpc, waves_per_block, win_rows,
-                               target_tasks, false, getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true, 10, P);
+        schpf::TileShape sh;
+        sh.lpc = lpc; sh.waves_per_block = waves_per_block; sh.win_rows = win_rows; sh.target_tasks = target_tasks;
+        sh.row_slots = 10;   // 160-byte table rows
+        sh.ring = ring; sh.slot_bytes = slot_bytes;
+        sh.allow_packed = getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true;
+        schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, false, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
         int64_t n = 0;
         for (int64_t t = 0; t < P.n_tasks; ++t) {
@@ -1332,31 +1574,48 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                 int64_t off = P.task_wave_off[(size_t)t * wpb + v];
                 for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                     const int steps = P.steps[((size_t)b * wpb + v) * W + w];
+                    if (P.ring > 1 && steps != P.steps[((size_t)b * wpb) * W + w])
+                        throw std::logic_error("ring plan: the waves of a block disagree on an epoch's steps");
                     for (int p = 0; p < steps; ++p)
                         for (int grp = 0; grp < gpw; ++grp)
                             for (int u = 0; u < 2; ++u) {
                                 float f;
-                                uint32_t local;
+                                uint32_t off16;
                                 if (P.packed) {
                                     const uint32_t *e = P.entries.data() + ((size_t)off + (size_t)p * gpw + grp) * 2;
-                                    local = (e[0] >> (16 * u)) & 0xFFFFu;
+                                    off16 = (e[0] >> (16 * u)) & 0xFFFFu;
                                     f = (float)((e[1] >> (16 * u)) & 0xFFFFu);
                                 } else {
                                     const uint32_t *e = P.entries.data() + ((size_t)off + (size_t)p * gpw + grp) * 4 + (size_t)u * 2;
-                                    local = e[0];
+                                    off16 = e[0];
                                     std::memcpy(&f, &e[1], 4);
                                 }
+                                int mn;   // the kernel's reconstruction (sweep_impl.h entry_minor)
+                                if (P.ring > 1) {
+                                    const int slot = (int)(off16 / (uint32_t)P.slot16);
+                                    const int r = (int)((off16 - (uint32_t)slot * P.slot16) / (uint32_t)P.row_slots);
+                                    const int ahead = (slot - w % P.ring + P.ring) % P.ring;
+                                    // readable in epoch w: sub-windows w .. w + ring - 2, inside the task
+                                    if (slot >= P.ring || ahead > P.ring - 2 || w + ahead >= P.task_w1[(size_t)t])
+                                        throw std::logic_error("ring plan: an entry points outside the readable slots");
+                                    if (f == 0.0f && off16 != (uint32_t)(w % P.ring) * (uint32_t)P.slot16)
+                                        throw std::logic_error("ring plan: padding must point at the epoch's own slot");
+                                    mn = (w + ahead) * P.win_rows + r;
+                                } else {
+                                    mn = w * P.win_rows + (int)(off16 / (uint32_t)P.row_slots);
+                                }
                                 if (f == 0.0f) continue;
+                                if (schpf::tile_off16(P, mn) != off16) throw std::logic_error("tile plan: bad LDS position");
                                 if (n >= nnz) throw std::logic_error("tile plan stores more nonzeros than given");
                                 const int g = v * gpw + grp;
                                 out_major[n] = P.block_rows[(size_t)b * gpb + g];
-                                out_minor[n] = (int32_t)(w * P.win_rows + (int)local);
+                                out_minor[n] = (int32_t)mn;
                                 out_val[n] = f;
                                 out_prow[n] = (int32_t)(t * gpb + g);
                                 out_task[n] = (int32_t)t;
                                 ++n;
                             }
-                    off += (int64_t)steps * gpw;
+                    off += schpf::tile_stored_steps(P, steps) * gpw;
                 }
             }
         }

@@ -27,7 +27,7 @@ template <typename T> struct SweepArgs {
 
 // LDS-staged sweep over a tile plan (plan.h, TilePlanHost)
 template <typename T> struct TileArgs {
-    const void *entries;           // uint4 {local0, val0, local1, val1} or packed uint2 (plan.h)
+    const void *entries;           // uint4 {off16_0, val0, off16_1, val1} or packed uint2 (plan.h)
     const uint16_t *steps;         // [(block * wpb + wave) * n_windows + window]
     const int *block_rows;         // [n_blocks * gpb]
     const int *task_block, *task_w0, *task_w1;
@@ -39,6 +39,7 @@ template <typename T> struct TileArgs {
     T *partials;                   // [n_tasks * gpb, KP]
     double *wave_out;              // [n_tasks * wpb] (LLH)
     int K, n_minor, n_windows, win_rows, wpb;
+    int ring, slot_bytes;          // ring mode (plan.h): slots in the LDS ring (<= 1: window mode), bytes per slot
     uint64_t seed;                 // MODE_RANDOM
     int major_is_cell;
 };
@@ -60,6 +61,9 @@ template <typename T> struct UpdateArgs {
     T *tab_e, *tab_log, *tab_exp;  // [n, KP]
     double *colsum_part;        // [nblocks, K]
 };
+
+// whether the sweep objects were compiled with the opt-in ring schedule (-DSCHPF_WITH_RING)
+bool ring_schedule_compiled();
 
 template <typename T>
 hipError_t launch_sweep(const SweepArgs<T> &a, int nv, int lpc, int mode, int64_t n_waves, hipStream_t st);

@@ -295,16 +295,17 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 
 // LDS-bank-aware order of one row segment (tile plan).  A lane group reads the gathered row with
 // ds_read_b128; the LDS serves 16 lanes (= 16/lpc lane groups, one "pass") per cycle and those
-// reads are conflict-free iff their 16-byte slots differ modulo 16.  A table row occupies
-// `row_slots` slots, so the slot base of local row r is (r * row_slots) mod 16 and its class is
-// base / lpc.  The group with rank j inside its pass wants class (j + t) mod n_classes at position
-// t: if every group of a pass gets its wish, the pass touches each slot once.  Greedy: take the
-// wished class if the segment still has such a nonzero, else from the fullest class.
+// reads are conflict-free iff their 16-byte slots differ modulo 16.  A row starts at LDS position
+// off16 (16-byte units, tile_off16), so its class is (off16 mod 16) / lpc.  The group with rank j
+// inside its pass wants class (j + t) mod n_classes at position t: if every group of a pass gets
+// its wish, the pass touches each slot once.  Greedy: take the wished class if the segment still
+// has such a nonzero, else from the fullest class.
 // seq[t] = index (within the segment) of the nonzero placed at position t.
-static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_slots, int lpc, int rank,
+static void bank_order(const TilePlanHost &P, const int32_t *seg_minor, int n, bool enabled, int rank,
                        std::vector<int32_t> &seq, std::vector<int32_t> &scratch)
 {
-    const int n_classes = std::max(1, 16 / std::max(1, lpc));   // a power of two (lpc is)
+    const int lpc = P.lpc;
+    const int n_classes = enabled ? std::max(1, 16 / std::max(1, lpc)) : 1;   // a power of two (lpc is)
     if (n_classes == 1 || n <= 2) {
         for (int t = 0; t < n; ++t) seq[(size_t)t] = t;
         return;
@@ -318,7 +319,7 @@ static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_sl
     scratch.resize((size_t)n * 2);
     int32_t *cls = scratch.data(), *pos = scratch.data() + n;
     for (int i = 0; i < n; ++i) {
-        const unsigned c = ((((unsigned)(seg_minor[i] - base) * (unsigned)row_slots) & 15u) >> lpc_shift) & cmask;
+        const unsigned c = ((tile_off16(P, seg_minor[i]) & 15u) >> lpc_shift) & cmask;
         cls[i] = (int32_t)c;
         cnt[c]++;
     }
@@ -345,13 +346,27 @@ static void bank_order(const int32_t *seg_minor, int n, int32_t base, int row_sl
 // ---- and the device builder (plan_device.hip)
 
 // dimensions, rows by length -> blocks, tasks, partial-row bookkeeping; P.steps zeroed
-void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, int lpc, int waves_per_block,
-                     int win_rows, int target_tasks, const int64_t *mptr)
+void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, const TileShape &shape,
+                     const int64_t *mptr)
 {
+    const int lpc = shape.lpc, waves_per_block = shape.waves_per_block, target_tasks = shape.target_tasks;
     if (lpc < 1 || lpc > 64 || (64 % lpc) != 0) throw std::invalid_argument("lpc must divide 64");
     if (waves_per_block < 1 || waves_per_block > 16) throw std::invalid_argument("waves_per_block in [1,16]");
-    if (win_rows < 1) throw std::invalid_argument("win_rows must be positive");
+    if (shape.row_slots < 1) throw std::invalid_argument("row_slots must be positive");
     P = TilePlanHost();
+    P.row_slots = shape.row_slots;
+    int win_rows = shape.win_rows;
+    if (shape.ring > 1) {
+        if (shape.ring < 3) throw std::invalid_argument("a ring needs at least 3 slots");
+        if (shape.slot_bytes < 16 * shape.row_slots || shape.slot_bytes % (1024 * waves_per_block))
+            throw std::invalid_argument("slot_bytes must hold a row and be a multiple of 1 KiB per wave");
+        P.ring = shape.ring;
+        P.slot16 = shape.slot_bytes / 16;
+        win_rows = P.slot16 / shape.row_slots;
+    }
+    if (win_rows < 1) throw std::invalid_argument("win_rows must be positive");
+    if ((int64_t)std::max(P.ring, 1) * std::max<int64_t>(P.slot16, (int64_t)win_rows * shape.row_slots) > 65536)
+        throw std::invalid_argument("the LDS window does not fit 16-bit positions");
     P.n_major = n_major;
     P.n_minor = n_minor;
     P.lpc = lpc;
@@ -420,7 +435,7 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
             for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                 int mx = 0;
                 for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, P.steps[((size_t)b * wpb + v) * W + w]);
-                work += mx + 2;
+                work += mx + (P.ring > 1 ? 1 : 2);
             }
             P.task_work[(size_t)t] = work;
         }
@@ -434,7 +449,7 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
     wave_off.assign((size_t)P.n_blocks * wpb + 1, 0);   // entries of (block, wave), window order
     for (size_t bw = 0; bw < (size_t)P.n_blocks * wpb; ++bw) {
         int64_t tot = 0;
-        for (int w = 0; w < W; ++w) tot += P.steps[bw * W + w];
+        for (int w = 0; w < W; ++w) tot += tile_stored_steps(P, P.steps[bw * W + w]);
         wave_off[bw + 1] = wave_off[bw] + tot * gpw;
     }
     P.task_wave_off.resize((size_t)P.n_tasks * wpb);
@@ -446,7 +461,7 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
                 for (int w = 0; w < W; ++w) {
                     const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
                     if (w % wpt == 0) P.task_wave_off[tv] = off;
-                    off += (int64_t)P.steps[bw * W + w] * gpw;
+                    off += tile_stored_steps(P, P.steps[bw * W + w]) * gpw;
                 }
             }
     });
@@ -492,9 +507,40 @@ void tile_plan_report(const TilePlanHost &P)
             (long long)wave_steps, wave_steps ? (double)wave_steps / (double)barrier_steps : 0.0);
 }
 
+// Ring-mode schedule of one block (plan.h): for every epoch e the steps T_e all waves run, and for
+// every lane how many of its row's nonzeros (in minor order) it has consumed BEFORE epoch e.
+//   start[g * (W + 1) + e], e = 0..W;  T[e]
+// Greedy: T_e = ceil(max over lanes of the nonzeros still owed up to sub-window e, / 2), rounded up
+// to a multiple of 4; every lane
+// then takes min(2 T_e, what lies inside the readable horizon min(e + ring - 1, task end)).
+// cnt_below(g, bound) = number of the lane's nonzeros with minor < bound * win_rows.
+template <typename CntBelow>
+static void ring_schedule_block(const TilePlanHost &P, int64_t b, CntBelow cnt_below, int32_t *start, uint32_t *T)
+{
+    const int W = P.n_windows, gpb = P.gpb, L = P.ring;
+    const int64_t wpt = P.windows_per_task;
+    std::vector<int32_t> done((size_t)gpb, 0);
+    for (int e = 0; e < W; ++e) {
+        const int w1 = (int)std::min<int64_t>((e / wpt + 1) * wpt, W);   // end of the task e belongs to
+        const int hor = std::min(e + L - 1, w1);
+        int32_t need = 0;
+        for (int g = 0; g < gpb; ++g) need = std::max(need, cnt_below(b, g, e + 1) - done[(size_t)g]);
+        // rounded up to the depth of the kernel's entry prefetch ring (4): an epoch then starts with
+        // its first entries in ring slots 0..3 and the prefetch distance survives the boundary.  The
+        // extra steps are not lost: rows with nonzeros inside the horizon work ahead in them.
+        const uint32_t Te = (uint32_t)(((need + 1) / 2 + 3) / 4 * 4);
+        T[e] = Te;
+        for (int g = 0; g < gpb; ++g) {
+            start[(size_t)g * (W + 1) + e] = done[(size_t)g];
+            const int32_t avail = cnt_below(b, g, hor) - done[(size_t)g];
+            done[(size_t)g] += std::min<int32_t>((int32_t)(2 * Te), avail);
+        }
+    }
+    for (int g = 0; g < gpb; ++g) start[(size_t)g * (W + 1) + W] = done[(size_t)g];
+}
+
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
-                     int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, bool allow_packed, int row_slots, TilePlanHost &P)
+                     int n_major, int n_minor, const TileShape &shape, bool keep_order, TilePlanHost &P)
 {
     const bool verbose = getenv("SCHPF_VERBOSE") && atoi(getenv("SCHPF_VERBOSE"));
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -503,8 +549,9 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     std::vector<int64_t> mptr;
     sort_by_major_minor(nnz, major, minor, n_major, n_minor, order, mptr);
     const double t1 = now();
-    tile_plan_begin(P, nnz, n_major, n_minor, lpc, waves_per_block, win_rows, target_tasks, mptr.data());
-    const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb;
+    tile_plan_begin(P, nnz, n_major, n_minor, shape, mptr.data());
+    const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb, win_rows = P.win_rows;
+    const bool ring = P.ring > 1;
 
     // sorted copies: every later pass walks the rows' runs sequentially
     const int nth = host_threads();
@@ -519,36 +566,67 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     });
 
     const double t2 = now();
-    // per (block, wave, window): steps = ceil(longest segment / 2).  Threads own whole blocks.
     std::vector<int> err((size_t)nth + 1, 0);
-    parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int t) {
-        for (int64_t b = b0; b < b1; ++b)
-            for (int g = 0; g < gpb; ++g) {
-                const int32_t row = P.block_rows[(size_t)b * gpb + g];
-                if (row < 0) continue;
-                uint16_t *st = P.steps.data() + ((size_t)b * wpb + g / gpw) * W;
-                int64_t j = mptr[row];
-                const int64_t end = mptr[(size_t)row + 1];
-                while (j < end) {           // runs of equal window (the row is sorted by minor)
-                    const int32_t w = s_minor[(size_t)j] / win_rows;
-                    const int64_t bound = ((int64_t)w + 1) * win_rows;   // one division per run, not per nonzero
-                    int64_t s = j;
-                    while (j < end && s_minor[(size_t)j] < bound) ++j;
-                    const int64_t steps = (j - s + 1) / 2;   // two nonzeros per step
-                    if (steps > 65535) { err[(size_t)t] = 1; continue; }
-                    if (steps > st[w]) st[w] = (uint16_t)steps;
+    // ring mode: consumed-before-epoch counts of every lane, [n_blocks * gpb][W + 1]
+    BigVec<int32_t> starts;
+    if (ring) starts.resize((size_t)P.n_blocks * gpb * ((size_t)W + 1));
+    if (!ring) {
+        // per (block, wave, window): steps = ceil(longest segment / 2).  Threads own whole blocks.
+        parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int t) {
+            for (int64_t b = b0; b < b1; ++b)
+                for (int g = 0; g < gpb; ++g) {
+                    const int32_t row = P.block_rows[(size_t)b * gpb + g];
+                    if (row < 0) continue;
+                    uint16_t *st = P.steps.data() + ((size_t)b * wpb + g / gpw) * W;
+                    int64_t j = mptr[row];
+                    const int64_t end = mptr[(size_t)row + 1];
+                    while (j < end) {           // runs of equal window (the row is sorted by minor)
+                        const int32_t w = s_minor[(size_t)j] / win_rows;
+                        const int64_t bound = ((int64_t)w + 1) * win_rows;   // one division per run, not per nonzero
+                        int64_t s = j;
+                        while (j < end && s_minor[(size_t)j] < bound) ++j;
+                        const int64_t steps = (j - s + 1) / 2;   // two nonzeros per step
+                        if (steps > 65535) { err[(size_t)t] = 1; continue; }
+                        if (steps > st[w]) st[w] = (uint16_t)steps;
+                    }
+                }
+        });
+    } else {
+        parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int t) {
+            std::vector<int32_t> below((size_t)gpb * ((size_t)W + 1));   // nonzeros of lane g with window < w
+            std::vector<uint32_t> T((size_t)W);
+            for (int64_t b = b0; b < b1; ++b) {
+                for (int g = 0; g < gpb; ++g) {
+                    int32_t *bl = below.data() + (size_t)g * (W + 1);
+                    const int32_t row = P.block_rows[(size_t)b * gpb + g];
+                    if (row < 0) { std::fill(bl, bl + W + 1, 0); continue; }
+                    int64_t j = mptr[row];
+                    const int64_t r0 = j, end = mptr[(size_t)row + 1];
+                    for (int w = 0; w < W; ++w) {
+                        bl[w] = (int32_t)(j - r0);
+                        const int64_t bound = ((int64_t)w + 1) * win_rows;
+                        while (j < end && s_minor[(size_t)j] < bound) ++j;
+                    }
+                    bl[W] = (int32_t)(j - r0);
+                }
+                ring_schedule_block(P, b, [&](int64_t, int g, int w) { return below[(size_t)g * (W + 1) + w]; },
+                                    starts.data() + (size_t)b * gpb * ((size_t)W + 1), T.data());
+                for (int e = 0; e < W; ++e) {
+                    if (T[(size_t)e] > 65535u) { err[(size_t)t] = 1; continue; }
+                    for (int v = 0; v < wpb; ++v) P.steps[((size_t)b * wpb + v) * W + e] = (uint16_t)T[(size_t)e];
                 }
             }
-    });
+        });
+    }
     for (int e : err)
         if (e) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
 
     const double t3 = now();
     std::vector<int64_t> wave_off;
     const int64_t total_padded = tile_plan_offsets(P, wave_off);
-    // packed entries (8 bytes per step: two 16-bit window-local indices + two 16-bit counts) when
-    // every count fits 16 bits -- UMI counts do; otherwise 16 bytes per step (32-bit index, float)
-    bool packed = allow_packed && win_rows <= 65536;
+    // packed entries (8 bytes per step: two 16-bit LDS positions + two 16-bit counts) when
+    // every count fits 16 bits -- UMI counts do; otherwise 16 bytes per step (32-bit position, float)
+    bool packed = shape.allow_packed;
     if (packed) {
         std::vector<int> big((size_t)nth + 1, 0);
         parallel_for(nnz, nth, [&](int64_t b, int64_t e, int t) {
@@ -565,8 +643,28 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     parallel_for(total_padded * epw, nth, [&](int64_t b, int64_t e, int) {
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
-    // fill: walk each row's nonzeros in minor order; position inside its window segment = t
-    const std::vector<int> pass_rank = tile_pass_rank(lpc, gpw);
+    // ring mode: an unused step slot must still point at a row that is valid while it is read --
+    // the first row of the epoch's own slot (count 0: it contributes nothing)
+    if (ring)
+        parallel_for(P.n_blocks * wpb, nth, [&](int64_t bw0, int64_t bw1, int) {
+            for (int64_t bw = bw0; bw < bw1; ++bw) {
+                int64_t off = wave_off[(size_t)bw];
+                for (int w = 0; w < W; ++w) {
+                    const int64_t n = (int64_t)P.steps[(size_t)bw * W + w] * gpw;
+                    const uint32_t o16 = (uint32_t)(w % P.ring) * (uint32_t)P.slot16;
+                    for (int64_t q = off; q < off + n; ++q) {
+                        if (packed) P.entries[(size_t)q * 2] = o16 | (o16 << 16);
+                        else { P.entries[(size_t)q * 4] = o16; P.entries[(size_t)q * 4 + 2] = o16; }
+                    }
+                    off += tile_stored_steps(P, P.steps[(size_t)bw * W + w]) * gpw;
+                }
+            }
+        });
+    // fill: a segment = the nonzeros one lane consumes in one window (window mode: its row's
+    // nonzeros of that window; ring mode: what the schedule gave it in that epoch); inside a
+    // segment the nonzeros may be taken in any order, so they are dealt to the steps in an
+    // LDS-bank-aware order (see bank_order)
+    const std::vector<int> pass_rank = tile_pass_rank(P.lpc, gpw);
     parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
         std::vector<int64_t> win_off((size_t)W);
         std::vector<int32_t> seq;
@@ -577,35 +675,42 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                 if (row < 0) continue;
                 const size_t bw = (size_t)b * wpb + g / gpw;
                 int64_t off = wave_off[bw];
-                for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += (int64_t)P.steps[bw * W + w] * gpw; }
+                for (int w = 0; w < W; ++w) { win_off[(size_t)w] = off; off += tile_stored_steps(P, P.steps[bw * W + w]) * gpw; }
                 const int slot = g % gpw;
-                // one window segment at a time; inside it the nonzeros may be taken in any order,
-                // so they are dealt to the steps in an LDS-bank-aware order (see bank_order)
+                const int32_t *st = ring ? starts.data() + ((size_t)b * gpb + g) * ((size_t)W + 1) : nullptr;
                 int64_t j = mptr[row];
-                const int64_t end = mptr[(size_t)row + 1];
-                while (j < end) {
-                    const int32_t w = s_minor[(size_t)j] / win_rows;
-                    const int64_t bound = ((int64_t)w + 1) * win_rows;
-                    int64_t s = j;
-                    while (j < end && s_minor[(size_t)j] < bound) ++j;
+                const int64_t r0 = j, end = mptr[(size_t)row + 1];
+                int w = 0;
+                while (ring ? w < W : j < end) {
+                    int64_t s;
+                    if (ring) {
+                        s = r0 + st[w];
+                        j = r0 + st[w + 1];
+                    } else {
+                        w = s_minor[(size_t)j] / win_rows;
+                        const int64_t bound = ((int64_t)w + 1) * win_rows;
+                        s = j;
+                        while (j < end && s_minor[(size_t)j] < bound) ++j;
+                    }
                     const int n = (int)(j - s);
                     seq.resize((size_t)n);
-                    bank_order(s_minor.data() + s, n, w * win_rows, row_slots, lpc, pass_rank[(size_t)slot], seq, buckets);
+                    bank_order(P, s_minor.data() + s, n, shape.bank_order, pass_rank[(size_t)slot], seq, buckets);
                     for (int t = 0; t < n; ++t) {
                         const int64_t src = s + seq[(size_t)t];
-                        const int32_t mn = s_minor[(size_t)src];
+                        const uint32_t o16 = tile_off16(P, s_minor[(size_t)src]);
                         const size_t step_slot = (size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot;
                         if (packed) {
                             uint32_t *e = P.entries.data() + step_slot * 2;
                             const int sh = (t & 1) * 16;
-                            e[0] |= (uint32_t)(mn - w * win_rows) << sh;
+                            e[0] = (e[0] & ~(0xFFFFu << sh)) | (o16 << sh);
                             e[1] |= (uint32_t)s_val[(size_t)src] << sh;
                         } else {
                             uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
-                            e[0] = (uint32_t)(mn - w * win_rows);
+                            e[0] = o16;
                             e[1] = f2u(s_val[(size_t)src]);
                         }
                     }
+                    if (ring) ++w;
                 }
             }
         }

@@ -114,10 +114,35 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 //             first window
 //   partial row of (task t, group g) = t * gpb + g;  a major row's partial rows are
 //             pfirst[row] + j * pstride, j < pcount[row]
+//
+// An entry's index field is the LDS position of its minor row in 16-byte units (off16), so the
+// kernel addresses the row as lds + 16 * off16 whatever the mode.
+//
+// Two schedules share this layout:
+//
+//  * WINDOW mode (ring == 1): the whole LDS is one window of `win_rows` minor rows; per
+//    (block, wave, window) the steps are the longest row segment of the wave, and all waves meet
+//    at a barrier per window.  A row's nonzeros per window are Poisson-distributed, so the
+//    workgroup moves at the pace of the fullest of its rows in every window (measured at
+//    BASELINE C3: 0.68 of the slots carry nonzeros).  Kept for sparse x wide problems where a
+//    ring slot would hold a nonzero or two per row.
+//
+//  * RING mode (ring >= 3): the LDS is a ring of `ring` slots of slot16 * 16 bytes; a "window" is
+//    now a SUB-window of win_rows = slot rows, sub-window s lives in slot s mod ring.  The
+//    workgroup advances in EPOCHS, one per sub-window: during epoch e the slots hold sub-windows
+//    e .. e+ring-2 (readable) while e+ring-1 is copied in asynchronously.  An epoch lasts T_e
+//    steps for EVERY wave of the block, T_e = what the row furthest behind needs to finish
+//    sub-window e (rounded up to a multiple of 4, the depth of the kernel's entry prefetch); a row
+//    that has finished it spends the remaining steps on its nonzeros of the sub-windows ahead (up
+//    to e+ring-2, never beyond its task).  Rows that fall behind in one
+//    sub-window have usually worked ahead before: at C3 0.88-0.91 of the slots carry nonzeros,
+//    and the staging copy never stalls the compute.  steps[] then holds T_e for every wave.
 struct TilePlanHost {
     int n_major = 0, n_minor = 0;
     int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
     int win_rows = 0, n_windows = 0, windows_per_task = 0;
+    int ring = 1, slot16 = 0;             // ring mode: slots in the LDS ring, 16-byte units per slot
+    int row_slots = 0;                    // 16-byte units per table row (KP * sizeof(T) / 16)
     int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
     bool packed = false;                  // 8-byte entries {idx0|idx1<<16, cnt0|cnt1<<16} instead of 16-byte
     BigVec<uint32_t> entries;
@@ -132,11 +157,33 @@ struct TilePlanHost {
     std::vector<int64_t> mptr;            // [n_major + 1]
 };
 
-// row_slots: 16-byte slots per table row (KP * sizeof(T) / 16), for the LDS-bank-aware ordering of
-// the nonzeros inside a row segment (0 = keep minor order).
+// Shape of a tile plan.  row_slots: 16-byte units per table row (KP * sizeof(T) / 16).
+// ring <= 1: window mode with win_rows rows per window.  ring >= 3: ring mode, slot_bytes per ring
+// slot (win_rows is then derived: slot_bytes / row bytes).  bank_order: deal the nonzeros of a
+// segment to the steps in the LDS-bank-aware order (false = minor order).
+struct TileShape {
+    int lpc = 1, waves_per_block = 16, win_rows = 1, target_tasks = 0, row_slots = 1;
+    int ring = 1, slot_bytes = 0;
+    bool bank_order = true, allow_packed = true;
+};
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
-                     int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
-                     int target_tasks, bool keep_order, bool allow_packed, int row_slots, TilePlanHost &out);
+                     int n_major, int n_minor, const TileShape &shape, bool keep_order, TilePlanHost &out);
+
+// Step slots a (block, wave, window) occupies in the entry stream: ring mode pads every epoch to a
+// multiple of the kernel's prefetch-ring depth (4), so that the ring runs on across epoch
+// boundaries with every step in its slot (the padding steps are loaded, never executed).
+inline int64_t tile_stored_steps(const TilePlanHost &P, int steps)
+{
+    return P.ring > 1 ? (int64_t)((steps + 3) / 4 * 4) : (int64_t)steps;
+}
+
+// LDS position (16-byte units) of minor row m: shared by both builders and the test hook
+inline uint32_t tile_off16(const TilePlanHost &P, int32_t m)
+{
+    const int32_t w = m / P.win_rows;
+    const uint32_t r = (uint32_t)(m - w * P.win_rows) * (uint32_t)P.row_slots;
+    return P.ring > 1 ? (uint32_t)(w % P.ring) * (uint32_t)P.slot16 + r : r;
+}
 
 // positions sorted by (major, minor) and the per-major run pointers
 void sort_by_major_minor(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
@@ -151,8 +198,8 @@ void counting_sort_positions(int64_t n, const int32_t *key, int nkeys, BigVec<in
                              std::vector<int64_t> &ptr);
 
 // pieces of build_tile_plan that do not touch the nonzeros (shared with the device builder)
-void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, int lpc, int waves_per_block,
-                     int win_rows, int target_tasks, const int64_t *mptr);
+void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, const TileShape &shape,
+                     const int64_t *mptr);
 int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off);
 std::vector<int> tile_pass_rank(int lpc, int gpw);
 void tile_plan_report(const TilePlanHost &P);
@@ -164,9 +211,8 @@ void coo_order_flags(int64_t nnz, const int32_t *major, const int32_t *minor, bo
 // plan_device.hip: the same plan built by device passes over an uploaded COO (hipStream_t is a
 // pointer type; declared as void * here so that host-only translation units need no HIP header)
 void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, const int32_t *d_minor,
-                            const float *d_val, bool presorted, bool packed_ok, int n_major, int n_minor, int lpc,
-                            int waves_per_block, int win_rows, int target_tasks, bool allow_packed, int row_slots,
-                            TilePlanHost &P, void **out_entries, size_t *out_entries_bytes, void **out_steps,
-                            void **out_order);
+                            const float *d_val, bool presorted, bool packed_ok, int n_major, int n_minor,
+                            const TileShape &shape, TilePlanHost &P, void **out_entries, size_t *out_entries_bytes,
+                            void **out_steps, void **out_order);
 
 }  // namespace schpf

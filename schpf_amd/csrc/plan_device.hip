@@ -70,7 +70,16 @@ __global__ void fill_i64_kernel(int64_t n, int64_t v, int64_t *__restrict__ out)
 
 struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
+    int ring, slot16, wpt;
 };
+
+// LDS position of minor row m in 16-byte units (plan.h tile_off16)
+__device__ __forceinline__ uint32_t dev_off16(const Geometry &g, int32_t m)
+{
+    const int32_t w = m / g.win_rows;
+    const uint32_t r = (uint32_t)(m - w * g.win_rows) * (uint32_t)g.row_slots;
+    return g.ring > 1 ? (uint32_t)(w % g.ring) * (uint32_t)g.slot16 + r : r;
+}
 
 // first position in [lo, hi) whose minor index is >= key (the row's minors ascend)
 __device__ __forceinline__ int64_t lower_bound_minor(const int32_t *__restrict__ s_minor, int64_t lo, int64_t hi, int64_t key)
@@ -108,9 +117,57 @@ __global__ void steps_kernel(Geometry g, int64_t n_slots, const int32_t *__restr
     atomicMax(steps32 + ((size_t)b * g.wpb + v) * g.W + w, (unsigned)steps);
 }
 
-__device__ __forceinline__ int bank_class(const Geometry &g, int32_t local)
+__device__ __forceinline__ int bank_class(const Geometry &g, int32_t minor)
 {
-    return (int)(((((unsigned)local * (unsigned)g.row_slots) & 15u) >> g.lpc_shift) & (unsigned)(g.n_classes - 1));
+    return (int)(((dev_off16(g, minor) & 15u) >> g.lpc_shift) & (unsigned)(g.n_classes - 1));
+}
+
+// Ring mode (plan.h): the schedule of one block, plan.cpp::ring_schedule_block with the block's
+// lanes as threads.  T_e goes to every wave's steps32 row, start[lane][e] = nonzeros the lane has
+// consumed before epoch e.
+__global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const int32_t *__restrict__ block_rows,
+                                                            const int64_t *__restrict__ mptr,
+                                                            const int32_t *__restrict__ s_minor,
+                                                            unsigned *__restrict__ steps32, int32_t *__restrict__ start,
+                                                            int *__restrict__ err)
+{
+    __shared__ int red[16];
+    const int64_t b = blockIdx.x;
+    const int gi = threadIdx.x;                       // lane group of the block; blockDim.x = gpb rounded up to waves
+    const bool owner = gi < g.gpb;
+    const int32_t row = owner ? block_rows[b * g.gpb + gi] : -1;
+    const int64_t r0 = row >= 0 ? mptr[row] : 0, r1 = row >= 0 ? mptr[row + 1] : 0;
+    int32_t *st = start + ((size_t)b * g.gpb + (owner ? gi : 0)) * ((size_t)g.W + 1);
+    int64_t c_need = r0, c_hor = r0;                  // first nonzero with window >= e + 1 / >= horizon
+    int32_t done = 0;
+    // galloping lower bound from a cursor: the cursors only move forward
+    auto advance = [&](int64_t from, int64_t bound) {
+        if (from >= r1 || (int64_t)s_minor[from] >= bound) return from;
+        int64_t step = 1, lo = from;                  // s_minor[lo] < bound
+        while (lo + step < r1 && (int64_t)s_minor[lo + step] < bound) { lo += step; step <<= 1; }
+        return lower_bound_minor(s_minor, lo + 1, lo + step < r1 ? lo + step : r1, bound);
+    };
+    for (int e = 0; e < g.W; ++e) {
+        const int w1 = min((e / g.wpt + 1) * g.wpt, g.W);
+        const int hor = min(e + g.ring - 1, w1);
+        c_need = advance(c_need, ((int64_t)e + 1) * g.win_rows);
+        if (c_hor < c_need) c_hor = c_need;
+        c_hor = advance(c_hor, (int64_t)hor * g.win_rows);
+        int need = (int)(c_need - r0) - done;
+        // block maximum
+        for (int m = 32; m >= 1; m >>= 1) need = max(need, __shfl_xor(need, m, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = need;
+        __syncthreads();
+        need = 0;
+        for (int v = 0; v < (int)(blockDim.x >> 6); ++v) need = max(need, red[v]);
+        __syncthreads();
+        const unsigned Te = (unsigned)(((need + 1) / 2 + 3) / 4 * 4);   // plan.cpp::ring_schedule_block
+        if (Te > 65535u) *err = 1;
+        if (gi < g.wpb) steps32[((size_t)b * g.wpb + gi) * g.W + e] = Te;
+        if (owner) st[e] = done;
+        done += min((int32_t)(2 * Te), (int32_t)(c_hor - r0) - done);
+    }
+    if (owner) st[g.W] = done;
 }
 
 // fill, one thread per (row, window) segment: the segment's nonzeros are dealt to the steps in the
@@ -120,7 +177,8 @@ __device__ __forceinline__ int bank_class(const Geometry &g, int32_t local)
 __global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restrict__ block_rows,
                             const int64_t *__restrict__ mptr, const int32_t *__restrict__ s_minor,
                             const float *__restrict__ s_val, const int64_t *__restrict__ win_off,
-                            const int *__restrict__ pass_rank, uint32_t *__restrict__ entries)
+                            const int *__restrict__ pass_rank, const int32_t *__restrict__ start,
+                            uint32_t *__restrict__ entries)
 {
     const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (id >= n_slots * g.W) return;
@@ -130,9 +188,16 @@ __global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restri
     if (row < 0) return;
     const int64_t r0 = mptr[row], r1 = mptr[row + 1];
     if (r0 == r1) return;
-    const int32_t base = w * g.win_rows;
-    const int64_t s = lower_bound_minor(s_minor, r0, r1, (int64_t)base);
-    const int64_t e_ = lower_bound_minor(s_minor, s, r1, (int64_t)base + g.win_rows);
+    int64_t s, e_;
+    if (g.ring > 1) {   // ring mode: what the schedule gave this lane in epoch w
+        const int32_t *st = start + (size_t)slot * ((size_t)g.W + 1);
+        s = r0 + st[w];
+        e_ = r0 + st[w + 1];
+    } else {
+        const int32_t base = w * g.win_rows;
+        s = lower_bound_minor(s_minor, r0, r1, (int64_t)base);
+        e_ = lower_bound_minor(s_minor, s, r1, (int64_t)base + g.win_rows);
+    }
     const int n = (int)(e_ - s);
     if (n == 0) return;
     const int64_t b = slot / g.gpb;
@@ -146,7 +211,7 @@ __global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restri
     int64_t cur[16];
     for (int c = 0; c < 16; ++c) { cnt[c] = 0; cur[c] = s; }
     if (ordered)
-        for (int64_t j = s; j < e_; ++j) cnt[bank_class(g, s_minor[j] - base)]++;
+        for (int64_t j = s; j < e_; ++j) cnt[bank_class(g, s_minor[j])]++;
     for (int t = 0; t < n; ++t) {
         int64_t src;
         if (!ordered) {
@@ -159,23 +224,38 @@ __global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restri
                     if (cnt[k] > best) { best = cnt[k]; c = k; }
             }
             int64_t q = cur[c];
-            while (bank_class(g, s_minor[q] - base) != c) ++q;   // next unused nonzero of class c, in minor order
+            while (bank_class(g, s_minor[q]) != c) ++q;   // next unused nonzero of class c, in minor order
             src = q;
             cur[c] = q + 1;
             cnt[c]--;
         }
-        const int32_t mn = s_minor[src];
+        const uint32_t o16 = dev_off16(g, s_minor[src]);
         const size_t step_slot = (size_t)off + (size_t)(t >> 1) * g.gpw + gslot;
         if (g.packed) {
             uint32_t *e = entries + step_slot * 2;
             const int sh = (t & 1) * 16;
-            e[0] |= (uint32_t)(mn - base) << sh;
+            e[0] = (e[0] & ~(0xFFFFu << sh)) | (o16 << sh);
             e[1] |= (uint32_t)s_val[src] << sh;
         } else {
             uint32_t *e = entries + step_slot * 4 + (size_t)(t & 1) * 2;
-            e[0] = (uint32_t)(mn - base);
+            e[0] = o16;
             e[1] = __float_as_uint(s_val[src]);
         }
+    }
+}
+
+// ring mode: unused step slots point at the first row of their epoch's own slot (plan.cpp)
+__global__ void ring_pad_kernel(Geometry g, int64_t n_bw, const int64_t *__restrict__ win_off,
+                                const unsigned *__restrict__ steps32, uint32_t *__restrict__ entries)
+{
+    const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (id >= n_bw * g.W) return;
+    const int w = (int)(id % g.W);
+    const int64_t off = win_off[id], n = (int64_t)steps32[id] * g.gpw;
+    const uint32_t o16 = (uint32_t)(w % g.ring) * (uint32_t)g.slot16;
+    for (int64_t q = off; q < off + n; ++q) {
+        if (g.packed) entries[(size_t)q * 2] = o16 | (o16 << 16);
+        else { entries[(size_t)q * 4] = o16; entries[(size_t)q * 4 + 2] = o16; }
     }
 }
 
@@ -191,11 +271,11 @@ inline unsigned grid_for(int64_t n, int threads)
 // entries stay empty), device buffers entries / steps (uint16) / order (int32, nullptr when
 // presorted: identity) that the caller owns and frees with hipFree.
 void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, const int32_t *d_minor,
-                            const float *d_val, bool presorted, bool packed_ok, int n_major, int n_minor, int lpc,
-                            int waves_per_block, int win_rows, int target_tasks, bool allow_packed, int row_slots,
-                            TilePlanHost &P, void **out_entries, size_t *out_entries_bytes, void **out_steps,
-                            void **out_order)
+                            const float *d_val, bool presorted, bool packed_ok, int n_major, int n_minor,
+                            const TileShape &shape, TilePlanHost &P, void **out_entries, size_t *out_entries_bytes,
+                            void **out_steps, void **out_order)
 {
+    const int lpc = shape.lpc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     *out_entries = nullptr; *out_steps = nullptr; *out_order = nullptr; *out_entries_bytes = 0;
     const int threads = 256;
@@ -239,13 +319,15 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         PD_CHECK(hipStreamSynchronize(st));
 
         // ---- 3. host: blocks, tasks
-        tile_plan_begin(P, nnz, n_major, n_minor, lpc, waves_per_block, win_rows, target_tasks, mptr.data());
+        tile_plan_begin(P, nnz, n_major, n_minor, shape, mptr.data());
         Geometry g{};
-        g.gpb = P.gpb; g.gpw = P.gpw; g.wpb = P.wpb; g.W = P.n_windows; g.win_rows = win_rows; g.lpc = lpc;
+        g.gpb = P.gpb; g.gpw = P.gpw; g.wpb = P.wpb; g.W = P.n_windows; g.win_rows = P.win_rows; g.lpc = lpc;
         g.lpc_shift = 0;
         while ((1 << g.lpc_shift) < lpc) ++g.lpc_shift;
-        g.n_classes = row_slots > 0 ? std::max(1, 16 / std::max(1, lpc)) : 1;
-        g.row_slots = row_slots;
+        g.n_classes = shape.bank_order ? std::max(1, 16 / std::max(1, lpc)) : 1;
+        g.row_slots = P.row_slots;
+        g.ring = P.ring; g.slot16 = P.slot16; g.wpt = P.windows_per_task;
+        const bool ring = P.ring > 1;
         const int64_t n_slots = P.n_blocks * P.gpb;
         Tmp d_rows((size_t)n_slots * 4);
         PD_CHECK(hipMemcpyAsync(d_rows.p, P.block_rows.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
@@ -256,9 +338,14 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         PD_CHECK(hipMemsetAsync(d_steps32.p, 0, n_steps * 4 + 4, st));
         int *d_err = d_steps32.as<int>() + n_steps;
         const int64_t n_segments = n_slots * P.n_windows;
-        if (n_segments > 0)
+        Tmp d_start(ring ? (size_t)n_slots * ((size_t)P.n_windows + 1) * 4 : 0);
+        if (n_segments > 0 && !ring)
             hipLaunchKernelGGL(steps_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
                                d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, d_steps32.as<unsigned>(), d_err);
+        if (n_segments > 0 && ring)
+            hipLaunchKernelGGL(ring_schedule_kernel, dim3((unsigned)P.n_blocks), dim3((unsigned)((P.gpb + 63) / 64 * 64)), 0, st, g,
+                               d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, d_steps32.as<unsigned>(),
+                               d_start.as<int32_t>(), d_err);
         std::vector<uint32_t> steps32(n_steps + 1);
         PD_CHECK(hipMemcpyAsync(steps32.data(), d_steps32.p, (n_steps + 1) * 4, hipMemcpyDeviceToHost, st));
         PD_CHECK(hipStreamSynchronize(st));
@@ -268,7 +355,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         // ---- 5. host: offsets
         std::vector<int64_t> wave_off;
         const int64_t total_padded = tile_plan_offsets(P, wave_off);
-        P.packed = allow_packed && win_rows <= 65536 && packed_ok;
+        P.packed = shape.allow_packed && packed_ok;
         g.packed = P.packed ? 1 : 0;
         const int epw = P.packed ? 2 : 4;
         const std::vector<int> pass_rank = tile_pass_rank(lpc, P.gpw);
@@ -289,16 +376,20 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
             int64_t off = wave_off[bw];
             for (int w = 0; w < P.n_windows; ++w) {
                 win_off[bw * P.n_windows + w] = off;
-                off += (int64_t)P.steps[bw * P.n_windows + w] * P.gpw;
+                off += tile_stored_steps(P, P.steps[bw * P.n_windows + w]) * P.gpw;
             }
         }
         Tmp d_woff(win_off.size() * 8), d_rank(pass_rank.size() * 4);
         PD_CHECK(hipMemcpyAsync(d_woff.p, win_off.data(), win_off.size() * 8, hipMemcpyHostToDevice, st));
         PD_CHECK(hipMemcpyAsync(d_rank.p, pass_rank.data(), pass_rank.size() * 4, hipMemcpyHostToDevice, st));
+        if (ring && n_steps > 0)
+            hipLaunchKernelGGL(ring_pad_kernel, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, st, g,
+                               (int64_t)P.n_blocks * P.wpb, d_woff.as<int64_t>(), d_steps32.as<unsigned>(),
+                               static_cast<uint32_t *>(d_entries));
         if (n_segments > 0)
             hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
                                d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, s_val, d_woff.as<int64_t>(),
-                               d_rank.as<int>(), static_cast<uint32_t *>(d_entries));
+                               d_rank.as<int>(), d_start.as<int32_t>(), static_cast<uint32_t *>(d_entries));
         PD_CHECK(hipGetLastError());
         PD_CHECK(hipStreamSynchronize(st));
         P.mptr.swap(mptr);

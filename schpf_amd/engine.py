@@ -151,6 +151,12 @@ class DeviceCAVI(object):
         _lib.check(self._lib.schpf_step(self._h, self._flags(freeze_genes, simultaneous,
                                                              cells_first=cells_first)))
 
+    def steps(self, n, freeze_genes=False, simultaneous=False, cells_first=False):
+        """n CAVI iterations in one call (the stretch between two loss checks); replayed as one
+        hipGraph from the second call with the same arguments."""
+        _lib.check(self._lib.schpf_steps(self._h, self._flags(freeze_genes, simultaneous,
+                                                              cells_first=cells_first), int(n)))
+
     def step_local(self, freeze_genes=False, simultaneous=False, side=None):
         """Sweeps of the sharded iteration.  side=None: both; 'gene': the gene-side sweep and the
         packing of its sums into the exchange buffer; 'cell': the cell-side sweep (so that the
@@ -160,6 +166,30 @@ class DeviceCAVI(object):
 
     def step_finish(self, freeze_genes=False, simultaneous=False):
         _lib.check(self._lib.schpf_step_finish(self._h, self._flags(freeze_genes, simultaneous, True)))
+
+    # ------------------------------------------------- sharded, collective inside the library
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes identifying a new RCCL communicator: generate on ONE rank, give to all."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().schpf_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Join the communicator (collective: returns once all `world` ranks have called it)."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        _lib.check(self._lib.schpf_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def steps_sharded(self, n, freeze_genes=False, simultaneous=False):
+        """n iterations of the sharded protocol with the all-reduce issued by the library."""
+        _lib.check(self._lib.schpf_steps_sharded(self._h, self._flags(freeze_genes, simultaneous), int(n)))
+
+    def loss_terms_all(self):
+        llh, gl, nnz = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._lib.schpf_loss_terms_all(self._h, ctypes.byref(llh), ctypes.byref(gl), ctypes.byref(nnz)))
+        return llh.value, gl.value, nnz.value
 
     def exchange_buffer(self):
         """(device pointer, element count) of the buffer to all-reduce between
@@ -199,8 +229,9 @@ class DeviceCAVI(object):
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(keys)}
 
     def plan_info(self):
-        info = (ctypes.c_int64 * 12)()
+        info = (ctypes.c_int64 * 16)()
         _lib.check(self._lib.schpf_plan_info(self._h, info))
         keys = ("KP", "KL", "LPC", "chunk_len", "windows_cell", "windows_gene", "n_chunks_cell",
-                "n_chunks_gene", "n_waves_cell", "n_waves_gene", "entry_slots_cell", "entry_slots_gene")
+                "n_chunks_gene", "n_waves_cell", "n_waves_gene", "entry_slots_cell", "entry_slots_gene",
+                "ring_cell", "ring_gene", "ring_slot_bytes", "waves_per_block")
         return dict(zip(keys, [int(v) for v in info]))

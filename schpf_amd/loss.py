@@ -30,8 +30,12 @@ def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_k
     loss checks) and evaluates `loss_function` on the projection.
     """
     from .scHPF_ import scHPF   # late import: scHPF_ imports this module
+    from .engine import DeviceCAVI
 
     pmodel = scHPF(nfactors=nfactors, **model_kwargs)
+    if not hasattr(X, "row"):
+        X = X.tocoo()
+    held = {}    # the held-out cells stay on the device between checks: one upload, one pair of plans
 
     def _projection_loss_function(*, a, ap, bp, c, cp, dp, eta, beta, **kwargs):
         assert eta.dims[0] == beta.dims[0]
@@ -44,8 +48,19 @@ def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_k
         proj_kwargs.setdefault("max_iter", 10)
         proj_kwargs.setdefault("min_iter", 10)
         proj_kwargs.setdefault("check_freq", proj_kwargs["max_iter"] + 1)
-        pmodel.project(X, replace=True, **proj_kwargs)
+        dtype = np.dtype(pmodel.dtype)
+        eng = held.get("engine")
+        if eng is None or eng.dtype != dtype or "engine" in proj_kwargs:
+            eng = proj_kwargs.get("engine")
+            if eng is None:
+                eng = DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype)
+                eng.upload(X)
+                held["engine"] = eng
+        pmodel.project(X, replace=True, **dict(proj_kwargs, engine=eng))
 
+        if getattr(loss_function, "func", loss_function) is mean_negative_pois_llh:   # also a functools.partial of it
+            # the engine holds exactly the state project() just returned: evaluate there (one scalar back)
+            return eng.mean_negative_pois_llh()
         return loss_function(X, a=pmodel.a, ap=pmodel.ap, bp=pmodel.bp, c=pmodel.c, cp=pmodel.cp,
                              dp=pmodel.dp, xi=pmodel.xi, eta=pmodel.eta, theta=pmodel.theta,
                              beta=pmodel.beta)

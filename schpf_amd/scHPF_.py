@@ -278,7 +278,8 @@ class scHPF(BaseEstimator):
     def _fit(self, X, freeze_genes=False, reinit=True, loss_function=None, min_iter=None,
              max_iter=None, epsilon=None, check_freq=None, single_process=False,
              checkstep_function=None, verbose=None, batchsize=None,
-             beta_theta_simultaneous=False, loss_smoothing=1, device=None, init="auto", engine=None):
+             beta_theta_simultaneous=False, loss_smoothing=1, device=None, init="auto", engine=None,
+             devices=None):
         """The CAVI loop (scHPF_.py:526-780) on the GPU.
 
         Keyword arguments are the reference's.  `single_process` is accepted and
@@ -287,7 +288,11 @@ class scHPF(BaseEstimator):
         ('numpy': t=0 responsibilities drawn with the NumPy global RNG exactly like
         the reference; 'device': drawn on the GPU; 'auto': numpy unless nnz*K is
         beyond what a host draw can reasonably do); `engine`, a DeviceCAVI that already holds
-        X (run_trials reuses one upload for all restarts).
+        X (run_trials reuses one upload for all restarts); `devices`, a list of HIP device
+        ordinals: with more than one the cells are row-sharded over those GPUs (nnz-balanced
+        blocks), every iteration does one RCCL all-reduce of the gene-side sums
+        (schpf_amd.sharded.ThreadedShards) and the result equals the single-GPU fit up to the
+        summation order of those sums.
         `batchsize` (minibatch CAVI, scHPF_.py:626-650, 688-695) runs every iteration on the
         device too, but re-uploads the batch's rows each iteration like the reference re-slices
         them -- it exists for behavioural parity, not speed (nothing in HBM-sized data needs it).
@@ -323,12 +328,21 @@ class scHPF(BaseEstimator):
                                        loss_function, max_iter, check_freq, checkstep_function, verbose,
                                        batchsize, beta_theta_simultaneous, device)
         own_engine = engine is None
-        eng = DeviceCAVI(ncells, ngenes, nfactors, dtype=model_dtype, device=device) if own_engine else engine
+        sharded = own_engine and devices is not None and len(devices) > 1
+        if devices is not None and len(devices) == 1:
+            device = int(devices[0])
+        if sharded:
+            from .sharded import ThreadedShards
+            import os
+            eng = ThreadedShards(X, nfactors, model_dtype, devices,      # uploads its row blocks itself
+                                 comm=os.environ.get("SCHPF_SHARD_COMM", "rccl"))
+        else:
+            eng = DeviceCAVI(ncells, ngenes, nfactors, dtype=model_dtype, device=device) if own_engine else engine
         if not own_engine and ((eng.ncells, eng.ngenes, eng.nfactors) != (ncells, ngenes, nfactors)
                                or eng.dtype != model_dtype or eng.nnz != X.data.shape[0]):
             raise ValueError("engine was built for a different matrix, nfactors or dtype")
         try:
-            if own_engine:
+            if own_engine and not sharded:
                 eng.upload(X)
             eng.set_hypers(a, c, bp, dp)
             for name, g in (("xi", xi), ("theta", theta), ("eta", eta), ("beta", beta)):
@@ -337,7 +351,11 @@ class scHPF(BaseEstimator):
             def download():
                 return [HPF_Gamma(*eng.get_gamma(n)) for n in ("xi", "eta", "theta", "beta")]
 
-            for t in range(max_iter):
+            # The reference's loop is `for t in range(max_iter): iterate; if t % check_freq == 0: check`
+            # (scHPF_.py:642-778).  Nothing on the host changes between two checks, so the stretch
+            # t .. next check runs as ONE library call (schpf_steps: one hipGraph launch).
+            t = 0
+            while t < max_iter:
                 if t == 0 and reinit:   # random responsibilities, scHPF_.py:652-655
                     use_host = init == "numpy" or (init == "auto"
                                                    and X.data.shape[0] * nfactors <= _HOST_PHI_LIMIT)
@@ -347,7 +365,11 @@ class scHPF(BaseEstimator):
                         del random_phi
                     else:
                         eng.init_phi_device(np.random.randint(0, 2 ** 31 - 1))
-                eng.step(freeze_genes=freeze_genes, simultaneous=beta_theta_simultaneous)
+                check_at = t if t % check_freq == 0 else (t // check_freq + 1) * check_freq
+                # (the reference also leaves after iteration self.max_iter when the local override is larger, :777)
+                last = min(check_at, max_iter - 1, max(self.max_iter, t))
+                eng.steps(last - t + 1, freeze_genes=freeze_genes, simultaneous=beta_theta_simultaneous)
+                t = last
 
                 if t % check_freq == 0:
                     if loss_function is None and checkstep_function is None:
@@ -371,6 +393,7 @@ class scHPF(BaseEstimator):
                         break
                 if t >= self.max_iter:
                     break
+                t += 1
 
             xi_new, eta_new, theta_new, beta_new = download()
         finally:

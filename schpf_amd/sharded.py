@@ -20,7 +20,7 @@ on CPU with the gloo backend and an oracle-backed engine (tests/test_sharded_cpu
 """
 import numpy as np
 
-__all__ = ["row_partition", "take_rows", "ShardedCAVI", "exchange_tensor_of"]
+__all__ = ["row_partition", "take_rows", "ShardedCAVI", "exchange_tensor_of", "ThreadedShards", "NativeShard"]
 
 
 def row_partition(X, world_size):
@@ -104,4 +104,145 @@ class ShardedCAVI(object):
         t = torch.tensor([llh, gl, float(nnz)], dtype=torch.float64, device=self.exchange.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         llh, gl, nnz = t.tolist()
+        return -(llh - gl) / nnz
+
+
+class ThreadedShards(object):
+    """One process, one host thread per GPU: the cells of X row-sharded over `devices`, every
+    shard a DeviceCAVI on its device, all of them ranks of one RCCL communicator that lives
+    inside the library (schpf_comm_init / schpf_steps_sharded).  This is what
+    `scHPF.fit(X, devices=[...])` drives; it presents the single-engine interface `_fit` uses
+    (set_hypers / set_gamma / get_gamma / init_phi_* / steps / mean_negative_pois_llh), with
+    cell-side arrays split by the row partition and gene-side arrays replicated.
+
+    ctypes releases the GIL during library calls, so the shards' launches really are issued
+    concurrently -- which the collective needs: every rank must enqueue its all-reduce.
+    """
+
+    def __init__(self, X, nfactors, dtype, devices, comm="rccl"):
+        """comm="rccl": the product path.  comm="emulated" (tests on a one-GPU box, where RCCL
+        refuses two ranks on one device): no communicator; the all-reduce is played by adding the
+        shards' exchange buffers through torch views -- same packing, same update kernels."""
+        from concurrent.futures import ThreadPoolExecutor
+        from .engine import DeviceCAVI
+        if not hasattr(X, "row"):
+            X = X.tocoo()
+        self.devices = list(devices)
+        self.world = len(self.devices)
+        if self.world < 2:
+            raise ValueError("ThreadedShards needs at least two devices")
+        self.dtype = np.dtype(dtype)
+        self.ncells, self.ngenes, self.nfactors = X.shape[0], X.shape[1], int(nfactors)
+        self.nnz = int(X.data.shape[0])
+        self.bounds = row_partition(X, self.world)
+        self._pool = ThreadPoolExecutor(max_workers=self.world)
+        self.keep = [None] * self.world          # positions of each shard's nonzeros in X (for init_phi_host)
+        self.comm = comm
+        uid = DeviceCAVI.comm_unique_id() if comm == "rccl" else None
+
+        def build(rank):
+            lo, hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
+            sub, keep = take_rows(X, lo, hi)
+            self.keep[rank] = keep
+            eng = DeviceCAVI(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
+            eng.upload(sub)
+            if uid is not None:
+                eng.comm_init(uid, rank, self.world)     # collective: all threads arrive here
+            return eng
+        self.engines = self._each(build)
+        if comm != "rccl":
+            self._views = [exchange_tensor_of(e, d) for e, d in zip(self.engines, self.devices)]
+
+    def _each(self, fn):
+        return list(self._pool.map(fn, range(self.world)))
+
+    def _rows(self, rank):
+        return slice(int(self.bounds[rank]), int(self.bounds[rank + 1]))
+
+    # ---- the DeviceCAVI interface used by scHPF._fit
+    def set_hypers(self, a, c, bp, dp):
+        self._each(lambda r: self.engines[r].set_hypers(a, c, bp, dp))
+
+    def set_gamma(self, name, vi_shape, vi_rate):
+        if name in ("xi", "theta"):
+            self._each(lambda r: self.engines[r].set_gamma(name, vi_shape[self._rows(r)], vi_rate[self._rows(r)]))
+        else:
+            self._each(lambda r: self.engines[r].set_gamma(name, vi_shape, vi_rate))
+
+    def get_gamma(self, name):
+        if name in ("eta", "beta"):             # identical on every rank
+            return self.engines[0].get_gamma(name)
+        parts = self._each(lambda r: self.engines[r].get_gamma(name))
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def init_phi_host(self, Xphi_data):
+        self._each(lambda r: self.engines[r].init_phi_host(Xphi_data[self.keep[r]]))
+
+    def init_phi_device(self, seed):
+        # cells differ between shards, so one seed gives independent draws per nonzero
+        self._each(lambda r: self.engines[r].init_phi_device(seed))
+
+    def steps(self, n, freeze_genes=False, simultaneous=False, cells_first=False):
+        if cells_first:
+            raise ValueError("the minibatch order is not available for sharded fits")
+        if self.comm == "rccl":
+            self._each(lambda r: self.engines[r].steps_sharded(n, freeze_genes=freeze_genes,
+                                                               simultaneous=simultaneous))
+            return
+        for _ in range(n):                       # emulated all-reduce (tests): same protocol, summed here
+            if not freeze_genes:
+                for e in self.engines:
+                    e.step_local(simultaneous=simultaneous, side="gene")
+                    e.synchronize()
+                total = self._views[0].clone()
+                for v in self._views[1:]:
+                    total += v.to(total.device)
+                for v in self._views:
+                    v.copy_(total.to(v.device))
+                import torch
+                torch.cuda.synchronize()
+                for e in self.engines:
+                    e.step_local(simultaneous=simultaneous, side="cell")
+            else:
+                for e in self.engines:
+                    e.step_local(freeze_genes=True, simultaneous=simultaneous)
+            for e in self.engines:
+                e.step_finish(freeze_genes=freeze_genes, simultaneous=simultaneous)
+
+    def mean_negative_pois_llh(self):
+        terms = self._each(lambda r: self.engines[r].loss_terms())   # same process: sum on the host
+        llh = sum(t[0] for t in terms); gl = sum(t[1] for t in terms); nnz = sum(t[2] for t in terms)
+        return -(llh - gl) / nnz
+
+    def close(self):
+        engines, self.engines = getattr(self, "engines", []), []
+        for e in engines:
+            e.close()
+        self._pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class NativeShard(object):
+    """One rank of a multi-process sharded fit (one process per GPU, e.g. under
+    torch.distributed.run) with the collective inside the library: same role as ShardedCAVI, one
+    library call per stretch of iterations instead of three calls and a torch collective per
+    iteration.  `unique_id` is DeviceCAVI.comm_unique_id() of rank 0, delivered by the caller."""
+
+    def __init__(self, engine, unique_id, rank, world):
+        self.engine = engine
+        engine.comm_init(unique_id, rank, world)
+
+    def step(self, freeze_genes=False, simultaneous=False):
+        self.engine.steps_sharded(1, freeze_genes=freeze_genes, simultaneous=simultaneous)
+
+    def steps(self, n, freeze_genes=False, simultaneous=False):
+        self.engine.steps_sharded(n, freeze_genes=freeze_genes, simultaneous=simultaneous)
+
+    def mean_negative_pois_llh(self):
+        llh, gl, nnz = self.engine.loss_terms_all()
         return -(llh - gl) / nnz

@@ -24,6 +24,8 @@ What each file pins (reference file:line):
   fit_*.npz            whole scHPF.fit()/project() traces (scHPF_.py:425-503,
                        526-780): bp, dp, per-check loss, final xi/theta/eta/beta
   trials_data_k5_f64.npz  run_trials / run_trials_pool (scHPF_.py:968-1332): winner and losses
+  trials_validation_k5_f64.npz  run_trials(vcells=...): the validation-loss trace of
+                       projection_loss_function (loss.py:37-102)
   pbmc_like_data.npz   the COO the reference's loader makes of its own test data
                        file tests/_data/PJ030merge...matrix.txt (data only)
   ref_model_f64.joblib a model file written by the reference's save_model
@@ -164,7 +166,26 @@ def make_trials(X, fname):
     np.savez_compressed(os.path.join(HERE, fname), **d)
 
 
+def make_validation(X, fname):
+    """run_trials with held-out validation cells (scHPF_.py:1097-1106 -> loss.py:37-102
+    projection_loss_function): the model trains on the first 70 cells; at every check the last
+    30 are projected onto the current eta/beta (warm-started from the previous projection) and
+    THEIR mean negative llh is the loss that drives the stop rule."""
+    import schpf as ref
+    csr = X.tocsr()
+    Xt, Xv = csr[:70].tocoo(), csr[70:].tocoo()
+    np.random.seed(21)
+    model = ref.run_trials(Xt, 5, ntrials=1, max_iter=40, verbose=False, vcells=Xv)
+    d = trace(model, Xt, model.loss, dict(seed=21, n_train=70))
+    np.savez_compressed(os.path.join(HERE, fname), **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "validation":
+        txt = "/root/reference/tests/_data/PJ030merge.c300t400_g0t500.matrix.txt"
+        Xd, _genes = prep.load_txt(txt, verbose=False)
+        make_validation(Xd, "trials_validation_k5_f64.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "trials":
         txt = "/root/reference/tests/_data/PJ030merge.c300t400_g0t500.matrix.txt"
         Xd, _genes = prep.load_txt(txt, verbose=False)
@@ -193,6 +214,7 @@ def main():
              batchsize=32)
     make_project(m64, Xd, "project_data_k5_f64.npz")
     make_trials(Xd, "trials_data_k5_f64.npz")
+    make_validation(Xd, "trials_validation_k5_f64.npz")
     schpf.save_model(m64, os.path.join(HERE, "ref_model_f64.joblib"))
     print("golden vectors written to", HERE)
 

@@ -101,7 +101,7 @@ def test_plan_empty_rows_and_single_nonzero():
     assert list(cptr) == [0, 0, 0, 0, 1, 1, 1] and stats[0] == 1
 
 
-def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_tasks):
+def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_tasks, ring=1, slot_bytes=0):
     lib = _lib.load()
     nnz = len(val)
     major = np.ascontiguousarray(major, np.int32)
@@ -113,23 +113,32 @@ def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_
     stats = (ctypes.c_int64 * 6)()
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     _lib.check(lib.schpf_debug_tile_expand(nnz, p(major), p(minor), p(val), n_major, n_minor, lpc, wpb,
-                                           win_rows, target_tasks, p(om), p(on), p(ov), p(oprow), p(otask),
+                                           win_rows, target_tasks, ring, slot_bytes, p(om), p(on), p(ov), p(oprow), p(otask),
                                            p(pfirst), p(pcount), stats))
     return om, on, ov, oprow, otask, pfirst, pcount, [int(s) for s in stats]
 
 
-@pytest.mark.parametrize("lpc,wpb,win_rows,tasks", [(4, 8, 64, 64), (2, 4, 37, 1), (1, 1, 1000, 7), (8, 2, 5, 1000),
-                                                  (16, 8, 300, 16)])
+# (lpc, waves per block, rows per window, target tasks, ring slots, bytes per slot): ring 1 = window
+# schedule; ring >= 3 = ring schedule, whose rows per sub-window follow from the slot (160-byte rows)
+@pytest.mark.parametrize("lpc,wpb,win_rows,tasks,ring,slot_bytes",
+                         [(4, 8, 64, 64, 1, 0), (2, 4, 37, 1, 1, 0), (1, 1, 1000, 7, 1, 0), (8, 2, 5, 1000, 1, 0),
+                          (16, 8, 300, 16, 1, 0),
+                          (2, 4, 0, 16, 5, 8192), (1, 1, 0, 1, 3, 1024), (4, 8, 0, 64, 4, 16384), (2, 16, 0, 1000, 5, 32768),
+                          (1, 2, 0, 7, 8, 2048)])
 @pytest.mark.parametrize("coo_order", ["shuffled", "row-major", "col-major"])
-def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, coo_order):
+def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_order):
     X = synthetic_counts(257, 1031, 0.04, seed=5)
     # the plan builder has fast paths for input already sorted by (row, col) / (col, row)
     perm = {"shuffled": np.random.RandomState(0).permutation(X.nnz),
             "row-major": np.lexsort((X.col, X.row)), "col-major": np.lexsort((X.row, X.col))}[coo_order]
     row, col, val = X.row[perm], X.col[perm], X.data[perm].astype(np.float32)
     for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
-        om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, tasks)
+        om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, tasks,
+                                                                   ring, slot_bytes)
         n_tasks, n_blocks, n_windows, pstride, slots, wpt = st
+        if ring > 1:
+            win_rows = slot_bytes // 160     # rows of a ring slot; the hook itself checks that every entry of
+            #                                  an epoch lies in a slot that is readable during that epoch
         key_in = np.sort(major.astype(np.int64) * nm + minor)
         key_out = np.sort(om.astype(np.int64) * nm + on)
         assert np.array_equal(key_in, key_out)                       # every nonzero exactly once

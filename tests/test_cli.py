@@ -1,0 +1,88 @@
+"""The `scHPF` command line (schpf_amd/cli.py): same sub-commands, options and output file names
+as the reference's bin/scHPF for train / score / project."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden, golden_coo
+
+
+def run_cli(*argv):
+    from schpf_amd import cli
+    return cli.main(list(argv))
+
+
+def test_parser_has_the_reference_options():
+    from schpf_amd import cli
+    p = cli._parser()
+    a = p.parse_args(["train", "-i", "x.mtx", "-k", "7", "-t", "3", "-M", "50", "-m", "5", "-e", "0.1", "-f", "5",
+                      "-a", "-2", "--float32", "-bs", "100", "-sl", "4", "-bts", "-sa", "-rp", "--quiet"])
+    assert (a.nfactors, a.ntrials, a.max_iter, a.min_iter, a.check_freq, a.batchsize, a.smooth_loss) == \
+        (7, 3, 50, 5, 5, 100, 4)
+    assert a.float32 and a.beta_theta_simultaneous and a.save_all and a.reproject and not a.verbose
+    assert p.parse_args(["train-pool", "-i", "x", "-k", "5", "6", "7"]).nfactors == [5, 6, 7]
+    b = p.parse_args(["project", "-m", "m.joblib", "-i", "x.mtx"])
+    assert (b.max_iter, b.min_iter, b.check_freq, b.recalc_bp) == (500, 10, 10, False)     # bin/scHPF:276-289
+
+
+def test_score_writes_the_reference_files(tmp_path):
+    """`scHPF score` needs no GPU: scores of a model file written by the REFERENCE."""
+    model = os.path.join(GOLDEN, "ref_model_f64.joblib")
+    genes = tmp_path / "genes.txt"
+    import joblib
+    m = joblib.load(model)
+    G = m.ngenes
+    genes.write_text("".join("ENSG%05d\tgene%d\n" % (i, i) for i in range(G)))
+    assert run_cli("score", "-m", model, "-o", str(tmp_path / "out"), "-p", "run1", "-g", str(genes)) == 0
+    out = tmp_path / "out"
+    cs = np.loadtxt(out / "run1.cell_score.txt", delimiter="\t")
+    gs = np.loadtxt(out / "run1.gene_score.txt", delimiter="\t")
+    np.testing.assert_allclose(cs, m.cell_score())
+    np.testing.assert_allclose(gs, m.gene_score())
+    ranked = np.loadtxt(out / "run1.ranked_genes.txt", dtype=str, delimiter="\t")
+    assert ranked.shape == gs.shape and ranked[0, 0] == "gene%d" % int(np.argmax(gs[:, 0]))
+    frac = np.loadtxt(out / "run1.mean_cellscore_fraction.txt", skiprows=1)
+    assert frac.shape == (cs.shape[1], 2) and abs(frac[-1, 1] - 1.0) < 1e-12 and np.all(np.diff(frac[:, 1]) >= 0)
+    table = (out / "run1.maximum_overlaps.txt").read_text().splitlines()
+    assert table[0].split("\t") == ["ntop", "max_overlap", "p_max", "max2_overlap", "p_max2"] and len(table) == 11
+    assert (out / "run1.score_commandline_args.json").exists()
+
+
+def test_score_statistics_follow_their_definitions():
+    from schpf_amd.util import max_pairwise, mean_cellscore_fraction, mean_cellscore_fraction_list
+    rng = np.random.RandomState(0)
+    cs = rng.gamma(1.0, 1.0, (50, 6))
+    want = [np.mean(np.sort(cs, 1)[:, -n:].sum(1) / cs.sum(1)) for n in range(1, 7)]
+    np.testing.assert_allclose(mean_cellscore_fraction_list(cs), want)
+    np.testing.assert_allclose(mean_cellscore_fraction(cs, 2), want[1])
+    gs = rng.gamma(1.0, 1.0, (300, 5))
+    tops = np.argsort(gs, axis=0)[-40:]
+    pair = sorted(len(np.intersect1d(tops[:, i], tops[:, j])) for i in range(5) for j in range(i + 1, 5))
+    assert max_pairwise(gs, 40).overlap == pair[-1]
+    assert max_pairwise(gs, 40, second_greatest=True).overlap <= pair[-1]
+    assert 0.0 <= max_pairwise(gs, 40).p <= 1.0
+
+
+@pytest.mark.gpu
+def test_train_then_project_from_the_shell(tmp_path):
+    """bin/scHPF train -> model file with the reference's name -> bin/scHPF project on it."""
+    from scipy.io import mmwrite
+    g = load_golden("fit_data_k5_s0_f64.npz")
+    X = golden_coo(g)
+    mtx = tmp_path / "train.mtx"
+    mmwrite(str(mtx), X, field="integer")
+    exe = [sys.executable, os.path.join(ROOT, "bin", "scHPF")]
+    subprocess.check_call(exe + ["train", "-i", str(mtx), "-o", str(tmp_path / "m"), "-k", "5", "-t", "2", "-M", "30",
+                                 "--quiet"])
+    model_file = tmp_path / "m" / "scHPF_K5_2trials.joblib"
+    assert model_file.exists() and (tmp_path / "m" / "train_commandline_args.json").exists()
+    subprocess.check_call(exe + ["project", "-m", str(model_file), "-i", str(mtx), "--max-iter", "10"])
+    proj = tmp_path / "m" / "scHPF_K5_2trials.proj.joblib"
+    assert proj.exists()
+    import joblib
+    model, projected = joblib.load(model_file), joblib.load(proj)
+    assert projected.beta == model.beta and projected.theta.dims == model.theta.dims
+    assert len(model.loss) >= 2 and model.loss[-1] < model.loss[0]

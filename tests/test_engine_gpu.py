@@ -15,11 +15,21 @@ from conftest import load_golden, golden_coo, synthetic_counts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["tile", "gather"])
+@pytest.fixture(autouse=True, params=["tile", "ring", "gather"])
 def plan_kind(request, monkeypatch):
-    """Every engine test runs on both sweep implementations: the LDS-staged tile plan and
-    the L2-gather plan (selected by the library from SCHPF_PLAN at upload time)."""
-    monkeypatch.setenv("SCHPF_PLAN", request.param)
+    """Every engine test runs on all sweep implementations: the LDS-staged tile plan with the window
+    schedule ("tile", what ships), with the experimental ring schedule when the library was built
+    with it ("ring": SCHPF_RING=4), and the L2-gather plan (selected by the library from
+    SCHPF_PLAN at upload time)."""
+    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param == "ring" else request.param)
+    if request.param == "ring":
+        from schpf_amd import _lib
+        if b"+ring" not in _lib.load().schpf_version():
+            pytest.skip("the ring schedule is an opt-in experiment, not compiled into the shipped library "
+                        "(DEVFLAGS=-DSCHPF_WITH_RING tools/devbuild.sh)")
+        monkeypatch.setenv("SCHPF_RING", "4")
+    else:
+        monkeypatch.delenv("SCHPF_RING", raising=False)
     return request.param
 
 
@@ -423,7 +433,8 @@ def test_benchmarked_workloads_match_oracle_on_sampled_rows(amd, oracle, plan_ki
     size-independent conservation laws over ALL rows, (iii) the loss against the oracle's
     threaded compute_pois_llh over all nonzeros."""
     if plan_kind != "tile":
-        pytest.skip("the tile plan is the shipped path at this size; gather is covered by the small cases")
+        pytest.skip("'tile' lets the library choose the schedule, as bench.py does (the ring schedule at C3, "
+                    "the window schedule at the C5 share); forced variants are covered by the small cases")
     X = _bench_matrix(N, G, dens)
     a, c = 0.3, 0.3
     bp, dp, st = random_state(oracle, X, K, dtype, seed=0)
@@ -636,7 +647,7 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
     """One launch for both orientations (tile_sweep_dual_kernel) runs the same tasks with the same
     fixed-order reductions as one launch per orientation: identical bits, and run-to-run
     deterministic (no atomics anywhere)."""
-    if plan_kind != "tile":
+    if plan_kind == "gather":
         pytest.skip("the gather plan has no dual launch")
     X = synthetic_counts(3000, 2500, 0.04, seed=5)
     K = 20
@@ -660,7 +671,7 @@ def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_o
     fill) is the host builder's plan bit for bit: same entry order => same summation order => the
     engines agree in every bit after three iterations, from a host-drawn t=0 included (that path
     uses the plan's sort permutation)."""
-    if plan_kind != "tile":
+    if plan_kind == "gather":
         pytest.skip("the gather plan is always built on the host")
     from scipy.sparse import coo_matrix
     # col-major input also gets long segments (40 % filled: > 192 nonzeros per row and window)
@@ -684,3 +695,99 @@ def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_o
     assert results[0][4] == results[1][4]
     for (s0, r0), (s1, r1) in zip(results[0][:4], results[1][:4]):
         assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
+def test_steps_call_equals_single_steps_bitwise(amd, oracle, dtype, flags, plan_kind):
+    """schpf_steps(n) -- the stretch between two loss checks as one call, replayed as a hipGraph
+    from the second call on -- gives the bits of n schpf_step calls: eager first call, graph
+    capture, graph replay, an odd count (graph + one eager iteration), and after new
+    hyperparameters (which are baked into the captured launches and must invalidate them)."""
+    X = synthetic_counts(900, 700, 0.06, seed=31)
+    K, a, c = 20, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=3)
+    with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as one, load_engine(amd, X, K, dtype, st, a, c, bp, dp) as many:
+        def same():
+            for n in ("xi", "theta", "eta", "beta"):
+                (s0, r0), (s1, r1) = one.get_gamma(n), many.get_gamma(n)
+                assert np.array_equal(s0, s1) and np.array_equal(r0, r1), n
+        for count in (1, 4, 4, 4, 5, 2):
+            for _ in range(count):
+                one.step(**flags)
+            many.steps(count, **flags)
+            same()
+        one.set_hypers(a, c, bp * 1.5, dp * 0.5)
+        many.set_hypers(a, c, bp * 1.5, dp * 0.5)
+        for _ in range(4):
+            one.step(**flags)
+        many.steps(4, **flags)
+        same()
+        assert one.mean_negative_pois_llh() == many.mean_negative_pois_llh()
+
+
+def test_validation_cells_reproduce_reference_trace(amd):
+    """run_trials(vcells=...) (reference scHPF_.py:1097-1106, loss.py:37-102): held-out cells are
+    projected onto the model at every check, warm-started, and THEIR loss drives the stop rule.
+    Here the held-out cells stay resident in one engine between checks; the trace is the
+    reference's."""
+    from schpf import run_trials
+    g = load_golden("trials_validation_k5_f64.npz")
+    full = golden_coo(load_golden("pbmc_like_data.npz")).tocsr()
+    n_train = int(g["n_train"])
+    Xt, Xv = full[:n_train].tocoo(), full[n_train:].tocoo()
+    assert np.array_equal(Xt.data, g["x"]) and np.array_equal(Xt.col, g["col"])
+    np.random.seed(int(g["seed"]))
+    model = run_trials(Xt, 5, ntrials=1, max_iter=40, verbose=False, vcells=Xv)
+    assert len(model.loss) == len(g["loss"])
+    assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert_allclose(model.theta.vi_shape, g["theta_shape"], rtol=1e-6)
+    assert_allclose(model.beta.vi_rate, g["beta_rate"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("fname,dtype,kw", [FITS[0], FITS[3], FITS[5]])
+def test_fit_over_devices_reproduces_reference_trace(amd, monkeypatch, fname, dtype, kw):
+    """scHPF.fit(X, devices=[...]): cells row-sharded over the listed GPUs, one all-reduce of the
+    gene-side sums per iteration (schpf_amd.sharded.ThreadedShards).  The one-GPU test box cannot
+    host two RCCL ranks, so both shards sit on device 0 and the all-reduce is played through torch
+    views of the exchange buffers (SCHPF_SHARD_COMM=emulated); partitioning, packing, update
+    kernels and the estimator plumbing are the product's.  Same stop iteration and losses as the
+    reference's single-process run; parameters to the sharded summation order."""
+    from schpf import scHPF
+    monkeypatch.setenv("SCHPF_SHARD_COMM", "emulated")
+    g = load_golden(fname)
+    X = golden_coo(g)
+    np.random.seed(int(g["seed"]))
+    model = scHPF(int(g["nfactors"]), dtype=dtype, max_iter=int(g["max_iter"]), verbose=False)
+    model.fit(X, devices=[0, 0], **kw)
+    f32 = np.dtype(dtype) == np.float32
+    assert model.bp == float(g["bp"]) and model.dp == float(g["dp"])
+    assert len(model.loss) == len(g["loss"])
+    assert_allclose(model.loss, g["loss"], rtol=1e-4 if f32 else 1e-9)
+    for name in ("xi", "theta", "eta", "beta"):
+        got = getattr(model, name)
+        assert got.vi_shape.shape == g[name + "_shape"].shape
+        assert_allclose(got.vi_shape, g[name + "_shape"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
+        assert_allclose(got.vi_rate, g[name + "_rate"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
+
+
+def test_library_rccl_one_rank_equals_plain_steps(amd, oracle):
+    """The collective inside the library (schpf_comm_init / schpf_steps_sharded / schpf_loss_terms_all,
+    RCCL bound at run time to the copy already in the process): a one-rank communicator on the GPU
+    box.  The sharded iteration -- two sweep launches, packing, all-reduce on the communicator's
+    stream ordered by events, update from the exchange buffer -- must equal the oracle."""
+    from schpf_amd.sharded import NativeShard
+    X = synthetic_counts(700, 500, 0.06, seed=17)
+    K, a, c = 20, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=6)
+    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+        shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)
+        shard.steps(2)
+        shard.step(simultaneous=True)
+        shard.step(freeze_genes=True)
+        for flags in ({}, {}, {"simultaneous": True}, {"freeze_genes": True}):
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp, **flags)
+        compare_state(eng, st, rtol=1e-11)
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                             st.beta_shape, st.beta_rate)
+        assert_allclose(shard.mean_negative_pois_llh(), want, rtol=1e-11)
