@@ -4,7 +4,8 @@ run_trials and the model methods -- argument plumbing only, no logic of its own.
 Same sub-commands, options, defaults and output file names as the reference's script
 (/root/reference/bin/scHPF:134-292 options; :370-470 train, :485-534 score, :536-559 project),
 so a pipeline that calls `scHPF train -i X.mtx -o out -k 7 -t 5` keeps working and finds
-`out/scHPF_K7_5trials.joblib`.  `prep` / `prep-like` (gene filtering against annotation files)
+`out/scHPF_K7_b0_5trials.joblib` (the reference appends `_b{batchsize}` whenever ncells > batchsize,
+hence also for batchsize 0).  `prep` / `prep-like` (gene filtering against annotation files)
 are outside the accelerated path and are not provided.
 """
 import argparse

@@ -521,7 +521,7 @@ template <typename T> struct Engine final : schpf_ctx {
     void build_tiles_device(const int32_t *row, const int32_t *col, const float *val, bool packed_ok)
     {
         const double t0 = now_s();
-        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N);
+        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N, true);
         bool rc_sorted = true, cr_sorted = true;
         schpf::coo_order_flags(nnz, row, col, rc_sorted, cr_sorted);
         DevBuf d_row, d_col, d_val;
@@ -560,7 +560,7 @@ template <typename T> struct Engine final : schpf_ctx {
     // two workgroups per CU) until there are.  Measured on a 1/8 shard of C3 and on C2
     // (SCHPF_MIN_PAIRS = 768 / 256 / 128 / 64): the large workgroup wins well below one task per
     // CU, because both orientations share a launch and small windows cost padding and partials.
-    schpf::TileShape tile_shape(int n_major, int n_minor) const
+    schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false) const
     {
         int wpb = env_int("SCHPF_WPB", 0);
         int lds_kb = env_int("SCHPF_LDS_KB", 0);
@@ -616,7 +616,13 @@ template <typename T> struct Engine final : schpf_ctx {
         const int64_t lds_rows = sh.ring > 1 ? (int64_t)sh.win_rows * (sh.ring - 1) : sh.win_rows;
         const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
         const int64_t windows = ((int64_t)n_minor + lds_rows - 1) / lds_rows;
-        sh.target_tasks = env_int("SCHPF_TASKS", blocks * windows >= 2048 ? (wpb >= 12 ? 1024 : 2048) : 256);
+        // ... and half as many for an orientation with few blocks (the gene side of C3: 40 blocks of 512
+        // genes): 1024 tasks there are 26 window ranges per block = 26 partial rows per gene to write and
+        // to sum; 512 measured -3.5 % sweep, -15 % update time (profiles/r02/explore_tasks_per_side.log)
+        int dflt = blocks * windows >= 2048 ? (wpb >= 12 ? 1024 : 2048) : 256;
+        if (dflt >= 1024 && blocks < 64) dflt /= 2;
+        sh.target_tasks = env_int("SCHPF_TASKS", dflt);
+        sh.target_tasks = env_int(gene_side ? "SCHPF_TASKS_GENE" : "SCHPF_TASKS_CELL", sh.target_tasks);
         return sh;
     }
 
@@ -624,7 +630,7 @@ template <typename T> struct Engine final : schpf_ctx {
     // then uploaded one after the other on the context's stream
     void build_tiles(const int32_t *row, const int32_t *col, const float *val)
     {
-        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N);
+        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N, true);
         std::exception_ptr err;
         double secs_gene = 0.0;
         std::thread side([&] {

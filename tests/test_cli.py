@@ -77,10 +77,12 @@ def test_train_then_project_from_the_shell(tmp_path):
     exe = [sys.executable, os.path.join(ROOT, "bin", "scHPF")]
     subprocess.check_call(exe + ["train", "-i", str(mtx), "-o", str(tmp_path / "m"), "-k", "5", "-t", "2", "-M", "30",
                                  "--quiet"])
-    model_file = tmp_path / "m" / "scHPF_K5_2trials.joblib"
+    # the reference's name (bin/scHPF:446-449): "_b{batchsize}" is appended whenever ncells > batchsize,
+    # i.e. also for batchsize 0 -- a quirk scripts downstream rely on
+    model_file = tmp_path / "m" / "scHPF_K5_b0_2trials.joblib"
     assert model_file.exists() and (tmp_path / "m" / "train_commandline_args.json").exists()
     subprocess.check_call(exe + ["project", "-m", str(model_file), "-i", str(mtx), "--max-iter", "10"])
-    proj = tmp_path / "m" / "scHPF_K5_2trials.proj.joblib"
+    proj = tmp_path / "m" / "scHPF_K5_b0_2trials.proj.joblib"
     assert proj.exists()
     import joblib
     model, projected = joblib.load(model_file), joblib.load(proj)
