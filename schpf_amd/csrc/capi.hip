@@ -601,7 +601,7 @@ template <typename T> struct Engine final : schpf_ctx {
             const int slot_kb = 2 * wpb;                  // the kernel copies two 1 KiB pieces per wave and epoch
             int ring = std::min(lds_total / slot_kb, 8);
             if (ring_env > 1) ring = std::min(ring, ring_env);
-            const int64_t sub_rows = (int64_t)slot_kb * 1024 / (int64_t)row_bytes;
+            const int64_t sub_rows = ((int64_t)slot_kb * 1024 - 64) / (int64_t)row_bytes;
             const double per_row = (double)nnz / std::max(1, n_major) * (double)sub_rows / std::max(1, n_minor);
             if (ring >= 3 && sub_rows >= 1 && (int64_t)ring * slot_kb * 64 <= 65536 &&
                 (ring_env > 1 || per_row >= (double)env_int("SCHPF_RING_MIN_NNZ", 6))) {

@@ -358,11 +358,11 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     int win_rows = shape.win_rows;
     if (shape.ring > 1) {
         if (shape.ring < 3) throw std::invalid_argument("a ring needs at least 3 slots");
-        if (shape.slot_bytes < 16 * shape.row_slots || shape.slot_bytes % (1024 * waves_per_block))
+        if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % (1024 * waves_per_block))
             throw std::invalid_argument("slot_bytes must hold a row and be a multiple of 1 KiB per wave");
         P.ring = shape.ring;
         P.slot16 = shape.slot_bytes / 16;
-        win_rows = P.slot16 / shape.row_slots;
+        win_rows = (P.slot16 - 4) / shape.row_slots;   // the last 64 bytes of a slot stay free (kernel: counters)
     }
     if (win_rows < 1) throw std::invalid_argument("win_rows must be positive");
     if ((int64_t)std::max(P.ring, 1) * std::max<int64_t>(P.slot16, (int64_t)win_rows * shape.row_slots) > 65536)

@@ -794,9 +794,11 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 #ifdef SCHPF_WITH_RING
 // One workgroup = one task, ring schedule (plan.h): the LDS is a ring of a.ring slots; epoch w (one
 // per sub-window of the task) runs the same number of steps in EVERY wave while sub-window
-// w + ring - 1 is copied into the slot retired at the last barrier.  The step loop is the window
-// schedule's; what differs is the boundary: one barrier, no exposed staging, and the entry prefetch
-// ring runs on across it.
+// w + ring - 1 is copied into the slot of sub-window w - 1.  The step loop is the window schedule's;
+// what differs is the boundary: NO barrier -- two counters in LDS tell a wave when the rows it is
+// about to read have been stored and when the slot it is about to overwrite has been left by all
+// (a first version with a barrier per epoch lost more SIMD occupancy around its ~7-step barriers
+// than the schedule saves in padding) -- no exposed staging, and the entry prefetch ring runs on.
 template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const int task)
 {
@@ -862,11 +864,35 @@ __device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const
         stg0 = *reinterpret_cast<const uint4 *>(src);
         stg1 = *reinterpret_cast<const uint4 *>(src + piece);
     };
+    // the last 64 bytes of every slot hold no table row (plan.cpp: rows per slot); slot 0's carry the
+    // two counters that order the waves of the workgroup WITHOUT a barrier per epoch
+    const bool tail_lane = piece + wv * 1024 + lane * 16 + 16 > slot_bytes - 64;   // only in the second piece
     auto stage_store = [&](int sw) {
         unsigned char *dst = lds_raw + (size_t)(sw % L) * slot_bytes + (size_t)wv * 1024 + (size_t)lane * 16;
         *reinterpret_cast<uint4 *>(dst) = stg0;
-        *reinterpret_cast<uint4 *>(dst + piece) = stg1;
+        if (!tail_lane) *reinterpret_cast<uint4 *>(dst + piece) = stg1;
     };
+    // cnt[0] = (wave, epoch) completions, cnt[1] = (wave, copy) stores.  A wave that has finished
+    // epoch e adds 1 to cnt[0]; the slot of sub-window e may be overwritten once all wpb waves have
+    // (cnt[0] >= wpb * (e - w0 + 1)).  A wave that has stored its share of copy j (sub-window
+    // w0 + ring - 1 + j, made during epoch w0 + j) adds 1 to cnt[1]; the copy is readable once
+    // cnt[1] >= wpb * (j + 1).  LDS operations of one wave execute in issue order, so an add issued
+    // after the reads / writes it announces also happens after them.
+    unsigned *cnt = reinterpret_cast<unsigned *>(lds_raw + slot_bytes - 64);
+    auto counter = [&](int which) {
+        return (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_load(cnt + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    };
+    auto signal = [&](int which) {
+        if (lane == 0) __hip_atomic_fetch_add(cnt + which, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_for = [&](int which, unsigned target) {
+        // bounded (about a second): a protocol error must show up as a wrong result in the tests, not
+        // as a hung GPU
+        for (int spin = 0; counter(which) < target && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
+    };
+    const unsigned wpbu = (unsigned)a.wpb;
+    const int n_copies = max(0, (w1 - w0) - (L - 1));   // sub-windows beyond the ones staged up front
 
     E ring[RING];
     int steps = epoch_steps(w0);
@@ -877,7 +903,8 @@ __device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const
     if (MODE != MODE_RANDOM) {
         const int first_end = min(w0 + L - 1, w1);
         for (int sw = w0; sw < first_end; ++sw) { stage_load(sw); stage_store(sw); }   // readable in the first epoch
-        __syncthreads();
+        if (threadIdx.x == 0) { cnt[0] = 0u; cnt[1] = 0u; }
+        __syncthreads();                                   // the only barrier of the task
     }
 
     for (int w = w0; w < w1; ++w) {
@@ -885,6 +912,18 @@ __device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const
         // the sub-window copied during this epoch (into the slot retired at the last barrier); it
         // becomes readable in the next epoch
         const int stage_sw = (MODE != MODE_RANDOM && w + L - 1 < w1) ? w + L - 1 : -1;
+        const unsigned epoch_ix = (unsigned)(w - w0);
+        // this epoch reads up to sub-window w + ring - 2 = copy epoch_ix - 1: all shares stored?
+        if (MODE != MODE_RANDOM && epoch_ix >= 1u && n_copies > 0)
+            wait_for(1, wpbu * (unsigned)min((int)epoch_ix, n_copies));
+        bool stored = stage_sw < 0;
+        // the copy of this epoch goes into the slot of sub-window w - 1: free once every wave has
+        // finished epoch w - 1.  Tried once, with the last step of the first round (the pieces are in
+        // registers then); a wave that is more than a round ahead of the slowest one stores at the end
+        // of the epoch instead, after loading the pieces again.
+        auto try_store = [&]() {
+            if (!stored && counter(0) >= wpbu * epoch_ix) { stage_store(stage_sw); signal(1); stored = true; }
+        };
         if (PIPE) {
             // Rolling LDS pipeline, one nonzero deep: the minor rows of step p+1 are fetched from the
             // window while step p is still being computed -- row A' right after nonzero A has been
@@ -955,7 +994,7 @@ __device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (FIRST && i == RING - 1) { if (stage_sw >= 0) stage_store(stage_sw); }
+                    if (FIRST && i == RING - 1) try_store();
                 }
             };
             if (steps > 0) {
@@ -1047,20 +1086,22 @@ __device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const
                     // load of the unrolled ring to the top and spills
                     asm volatile("" ::: "memory");
                 }
-                if (i == RING - 1 && p == 0 && stage_sw >= 0) stage_store(stage_sw);
+                if (i == RING - 1 && p == 0) try_store();
             }
         }
         // an epoch's entries are stored padded to a multiple of RING steps (plan.cpp), so the ring
         // already holds the first steps of the next epoch in the right slots: no re-priming
         pos += (size_t)((steps + RING - 1) / RING * RING) * GPW;
-        if (w + 1 < w1) {
-            if (MODE != MODE_RANDOM) {
-                if (steps == 0 && stage_sw >= 0) { stage_load(stage_sw); stage_store(stage_sw); }   // empty epoch
-                // every wave has finished reading sub-window w and written its share of the copy
-                __syncthreads();
+        if (MODE != MODE_RANDOM && w + 1 < w1) {
+            if (!stored) {                                  // empty epoch, or this wave ran ahead
+                wait_for(0, wpbu * epoch_ix);
+                stage_load(stage_sw);
+                stage_store(stage_sw);
+                signal(1);
             }
-            steps = steps_next;
+            signal(0);                                      // every LDS read of this epoch has been issued
         }
+        if (w + 1 < w1) steps = steps_next;
     }
 
     if (MODE == MODE_LLH) {

@@ -407,25 +407,42 @@ class scHPF(BaseEstimator):
                        max_iter, check_freq, checkstep_function, verbose, batchsize,
                        beta_theta_simultaneous, device):
         """Minibatch CAVI (scHPF_.py:643-650, 688-704): each iteration updates a batch of cells
-        first (theta.rate from the current beta), then the genes from that batch alone."""
+        first (theta.rate from the current beta), then the genes from that batch alone.
+
+        One engine of `batchsize` cells lives for the whole fit: eta/beta and their tables stay on
+        the device from iteration to iteration; per iteration only the batch's rows are sent (the
+        plans of a batch are rebuilt by device passes, work proportional to the batch) together
+        with the batch's xi/theta rows, which come back after the step.  The default loss (all
+        cells) is evaluated by a second engine that holds the whole matrix for the whole fit."""
         from .util import minibatch_ix_generator
         nfactors = self.nfactors
         a, ap, c, cp = self.a, self.ap, self.c, self.cp
         Xcsr = X.tocsr()
         batches = minibatch_ix_generator(X.shape[0], batchsize)
-        if loss_function is None:
-            loss_function = ls.loss_function_for_data(ls.mean_negative_pois_llh, X)
         dtype = np.dtype(self.dtype)
-        for t in range(max_iter):
-            batch_ix = next(batches)
-            X_batch = Xcsr[batch_ix, :].tocoo()
-            with DeviceCAVI(len(batch_ix), X.shape[1], nfactors, dtype=dtype, device=device) as eng:
+        default_loss = loss_function is None
+        from contextlib import ExitStack
+        with ExitStack() as stack:
+            eng = stack.enter_context(DeviceCAVI(batchsize, X.shape[1], nfactors, dtype=dtype, device=device))
+            eng.set_hypers(a, c, bp, dp)
+            eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
+            eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
+            if default_loss:
+                whole = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
+                whole.upload(X)
+                whole.set_hypers(a, c, bp, dp)
+
+            def gene_side():      # eta.vi_shape is a constant of the model (:618); its rate and beta live on the device
+                if freeze_genes:
+                    return eta, beta
+                return HPF_Gamma(eta.vi_shape, eng.get_gamma("eta")[1]), HPF_Gamma(*eng.get_gamma("beta"))
+
+            for t in range(max_iter):
+                batch_ix = next(batches)
+                X_batch = Xcsr[batch_ix, :].tocoo()
                 eng.upload(X_batch)
-                eng.set_hypers(a, c, bp, dp)
                 eng.set_gamma("xi", xi.vi_shape[batch_ix], xi.vi_rate[batch_ix])
                 eng.set_gamma("theta", theta.vi_shape[batch_ix], theta.vi_rate[batch_ix])
-                eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
-                eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
                 if t == 0 and reinit:
                     random_phi = np.random.dirichlet(np.ones(nfactors), X_batch.data.shape[0])
                     eng.init_phi_host(X_batch.data[:, None] * random_phi)
@@ -434,24 +451,28 @@ class scHPF(BaseEstimator):
                 ths, thr = eng.get_gamma("theta")
                 theta.vi_shape[batch_ix], theta.vi_rate[batch_ix] = ths, thr
                 xi.vi_rate[batch_ix] = eng.get_gamma("xi")[1]
-                if not freeze_genes:
-                    beta = HPF_Gamma(*eng.get_gamma("beta"))
-                    eta = HPF_Gamma(eta.vi_shape, eng.get_gamma("eta")[1])
-            if t % check_freq == 0:
-                curr = loss_function(a=a, ap=ap, bp=bp, c=c, cp=cp, dp=dp, xi=xi, eta=eta, theta=theta,
-                                     beta=beta)
-                curr, pct = monitor.record(curr)
-                if verbose:
-                    print("[Iter. {0: >4}]  loss:{1:.6f}  pct:{2:.9f}".format(t, curr, pct))
-                if checkstep_function is not None:
-                    checkstep_function(bp=bp, dp=dp, xi=xi, eta=eta, theta=theta, beta=beta, t=t)
-                outcome = monitor.verdict(t)
-                if outcome is not None:
+                if t % check_freq == 0:
+                    eta, beta = gene_side()
+                    if default_loss:
+                        whole.set_gamma("theta", theta.vi_shape, theta.vi_rate)
+                        whole.set_gamma("beta", beta.vi_shape, beta.vi_rate)
+                        curr = whole.mean_negative_pois_llh()
+                    else:
+                        curr = loss_function(a=a, ap=ap, bp=bp, c=c, cp=cp, dp=dp, xi=xi, eta=eta, theta=theta,
+                                             beta=beta)
+                    curr, pct = monitor.record(curr)
                     if verbose:
-                        print(outcome)
+                        print("[Iter. {0: >4}]  loss:{1:.6f}  pct:{2:.9f}".format(t, curr, pct))
+                    if checkstep_function is not None:
+                        checkstep_function(bp=bp, dp=dp, xi=xi, eta=eta, theta=theta, beta=beta, t=t)
+                    outcome = monitor.verdict(t)
+                    if outcome is not None:
+                        if verbose:
+                            print(outcome)
+                        break
+                if t >= self.max_iter:
                     break
-            if t >= self.max_iter:
-                break
+            eta, beta = gene_side()
         return (bp, dp, xi, eta, theta, beta, monitor.loss)
 
     def _setup(self, X, freeze_genes=False, reinit=True, clip=True):

@@ -137,7 +137,7 @@ def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_or
                                                                    ring, slot_bytes)
         n_tasks, n_blocks, n_windows, pstride, slots, wpt = st
         if ring > 1:
-            win_rows = slot_bytes // 160     # rows of a ring slot; the hook itself checks that every entry of
+            win_rows = (slot_bytes - 64) // 160     # rows of a ring slot (its last 64 bytes stay free); the hook itself checks that every entry of
             #                                  an epoch lies in a slot that is readable during that epoch
         key_in = np.sort(major.astype(np.int64) * nm + minor)
         key_out = np.sort(om.astype(np.int64) * nm + on)
