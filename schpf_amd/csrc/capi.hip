@@ -434,6 +434,7 @@ template <typename T> struct Engine final : schpf_ctx {
             for (int v : nv_ok) if (v >= need) { nv = v; break; }
             if (!nv) continue;
             int cost;
+            if (want_tile && nv > 7) continue;                 // the tile sweeps are instantiated for <= 7 vectors
             if (want_tile) cost = (nv * 16 <= 112 || force_lpc) ? 0 : 1 << 20;   // first that fits
             else cost = nv * std::max(1, lpc / 4);
             if (cost < best_cost) { best_cost = cost; best_lpc = lpc; best_nv = nv; }

@@ -1282,6 +1282,23 @@ static hipError_t launch_random_t(const SweepArgs<T> &a, uint64_t seed, int majo
     default: return hipErrorInvalidValue;                                     \
     }
 #endif
+// the tile sweeps never see more than 7 vectors per lane (capi.hip choose_config: at most 112 row
+// bytes per lane); not instantiating 8 and 10 for them saves a fifth of this file's build time
+#ifdef SCHPF_DEV_FAST
+#define SCHPF_DISPATCH_TILE(nv, lpc, CALLEXPR) SCHPF_DISPATCH(nv, lpc, CALLEXPR)
+#else
+#define SCHPF_DISPATCH_TILE(nv, lpc, CALLEXPR)                                \
+    switch (nv) {                                                             \
+    case 1: { constexpr int NV = 1; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 2: { constexpr int NV = 2; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 3: { constexpr int NV = 3; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 4: { constexpr int NV = 4; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 5: { constexpr int NV = 5; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 6: { constexpr int NV = 6; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    case 7: { constexpr int NV = 7; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
+    default: return hipErrorInvalidValue;                                     \
+    }
+#endif
 
 template <typename T>
 hipError_t launch_sweep(const SweepArgs<T> &a, int nv, int lpc, int mode, int64_t n_waves, hipStream_t st)
@@ -1298,14 +1315,14 @@ template <typename T>
 hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int packed, int64_t n_tasks,
                              int threads, size_t lds_bytes, hipStream_t st)
 {
-    SCHPF_DISPATCH(nv, lpc, (launch_tile_t<T, NV, LPC>(a, mode, packed, n_tasks, threads, lds_bytes, st)))
+    SCHPF_DISPATCH_TILE(nv, lpc, (launch_tile_t<T, NV, LPC>(a, mode, packed, n_tasks, threads, lds_bytes, st)))
 }
 
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
                                   int packed, int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st)
 {
-    SCHPF_DISPATCH(nv, lpc, (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, st)))
+    SCHPF_DISPATCH_TILE(nv, lpc, (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, st)))
 }
 
 }  // namespace schpf

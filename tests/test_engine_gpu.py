@@ -562,6 +562,25 @@ def test_run_trials_reproduces_reference_selection(amd, capsys):
     assert len(m.loss) == 2 and np.isfinite(m.loss[-1])
 
 
+def test_run_trials_pool_threads_per_device(amd):
+    """run_trials_pool(devices=[...]): the restarts of every K are dealt to the devices, one host
+    thread and one resident upload per (K, device).  Two "devices" that are both GPU 0 exercise
+    the threaded path on a one-GPU box (the threads share NumPy's global RNG, so the draws
+    interleave: selection properties are checked, not a golden trace)."""
+    from schpf import run_trials_pool
+    X = golden_coo(load_golden("trials_data_k5_f64.npz"))
+    np.random.seed(5)
+    best, rejected = run_trials_pool(X, [4, 6], ntrials=4, max_iter=25, verbose=False, devices=[0, 0],
+                                     return_all=True)
+    assert [m.nfactors for m in best] == [4, 6] and [len(r) for r in rejected] == [3, 3]
+    for m, rest in zip(best, rejected):
+        finals = [m.loss[-1]] + [r.loss[-1] for r in rest]
+        assert np.all(np.isfinite(finals)) and finals == sorted(finals)       # winner first, rest ascending
+        for trial in [m] + rest:
+            assert trial.loss[-1] < trial.loss[0] and trial.theta.dims == (100, trial.nfactors)
+            assert np.all(trial.beta.vi_shape > 0) and np.all(trial.theta.vi_rate > 0)
+
+
 @pytest.mark.parametrize("stream_kind", ["engine-owned", "torch-default", "torch-side"])
 def test_rccl_all_reduce_accepts_the_exchange_buffer(amd, oracle, stream_kind):
     """One-rank NCCL(=RCCL) process group on the GPU box: the sharded driver's all_reduce runs
