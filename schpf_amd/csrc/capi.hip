@@ -285,6 +285,10 @@ template <typename T> struct Engine final : schpf_ctx {
     unsigned graph_flags = 0;
     int graph_n = 0;
     bool eager_since_upload = false;   // one eager iteration has run on this plan (kernel attributes are set)
+    // small problems: the update kernels sum the other side's per-block column sums themselves and the
+    // two reduce launches of an iteration are skipped; s_theta / s_beta are then brought up to date
+    // only when a path that reads them comes along (sums_stale)
+    bool sums_stale = false;
     static constexpr int UPD_BLOCKS = 2048;
     static constexpr size_t TABLE_PAD = 256 * 1024;
 
@@ -1052,9 +1056,19 @@ template <typename T> struct Engine final : schpf_ctx {
         const bool simultaneous = flags_ & SCHPF_SIMULTANEOUS;
         const bool sharded = flags_ & SCHPF_SHARDED;
         ScopedTimer tm(prof, stream, 3);
+        const bool cells_first = flags_ & SCHPF_CELLS_FIRST;
+        // default ordering on a small problem: no reduce launches (BASELINE C2: 2 of its 5 launches)
+        const bool fuse = !sharded && !freeze && !simultaneous && !cells_first && env_int("SCHPF_FUSE_SUMS", 1) &&
+                          (int64_t)upd_blocks(N) * K <= 16384 && (int64_t)upd_blocks(G) * K <= 16384;
+        if (!fuse && sums_stale) {   // s_theta / s_beta from the partials the last fused iteration left
+            HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), upd_blocks(N), K, s_theta.as<double>(),
+                                               exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
+            HIPCHK(schpf::launch_colsum_reduce(colpart_gene.as<double>(), upd_blocks(G), K, s_beta.as<double>(), nullptr,
+                                               0, stream));
+            sums_stale = false;
+        }
         // sharded: the all-reduced sum_i E[theta_ik] (old theta) is the tail of the exchange buffer
         if (sharded) widen_tail();
-        const bool cells_first = flags_ & SCHPF_CELLS_FIRST;
         auto gene_update = [&] {
         if (!freeze) {  // gene block, scHPF_.py:697-704 (or :668-673 + :682-685)
             schpf::UpdateArgs<T> u{};
@@ -1065,14 +1079,16 @@ template <typename T> struct Engine final : schpf_ctx {
             u.prior_shape = c;
             u.cap_shape = eta_s.as<T>(); u.cap_rate = eta_r.as<T>();
             u.s_other = s_theta.as<double>();
+            if (fuse) { u.s_other_part = colpart_cell.as<double>(); u.s_other_nb = upd_blocks(N); }
             u.cap_prior_rate = dp;
             u.shape = be_s.as<T>(); u.rate = be_r.as<T>(); u.cap_rate_out = eta_r.as<T>();
             u.tab_e = be_e.as<T>(); u.tab_log = be_log.as<T>(); u.tab_exp = be_exp.as<T>();
             u.colsum_part = colpart_gene.as<double>();
             const int nb = upd_blocks(G);
             HIPCHK(schpf::launch_gamma_update(u, src, nb, stream));
-            HIPCHK(schpf::launch_colsum_reduce(colpart_gene.as<double>(), nb, K, s_beta_next.as<double>(), nullptr,
-                                               0, stream));
+            if (!fuse)
+                HIPCHK(schpf::launch_colsum_reduce(colpart_gene.as<double>(), nb, K, s_beta_next.as<double>(), nullptr,
+                                                   0, stream));
         }
         };
         auto cell_update = [&] {
@@ -1087,19 +1103,22 @@ template <typename T> struct Engine final : schpf_ctx {
             // theta.rate uses the beta just updated (scHPF_.py:711-713) unless the updates are
             // simultaneous (:677-679) or the genes are frozen
             u.s_other = (freeze || simultaneous || cells_first) ? s_beta.as<double>() : s_beta_next.as<double>();
+            if (fuse) { u.s_other_part = colpart_gene.as<double>(); u.s_other_nb = upd_blocks(G); }
             u.cap_prior_rate = bp;
             u.shape = th_s.as<T>(); u.rate = th_r.as<T>(); u.cap_rate_out = xi_r.as<T>();
             u.tab_e = th_e.as<T>(); u.tab_log = th_log.as<T>(); u.tab_exp = th_exp.as<T>();
             u.colsum_part = colpart_cell.as<double>();
             const int nb = upd_blocks(N);
             HIPCHK(schpf::launch_gamma_update(u, src, nb, stream));
-            HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
-                                               exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
+            if (!fuse)
+                HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
+                                                   exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
         }
         };
         if (cells_first) { cell_update(); gene_update(); }   // minibatch order: theta first, beta from the NEW theta
         else { gene_update(); cell_update(); }
         if (!freeze) std::swap(s_beta.p, s_beta_next.p);
+        if (fuse) sums_stale = true;
         if (pending_init == 1) dense_cell.release();
         pending_init = 0;
         tm.stop();

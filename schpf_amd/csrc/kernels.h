@@ -54,7 +54,9 @@ template <typename T> struct UpdateArgs {
     double prior_shape;         // a or c
     const T *cap_shape;         // xi / eta shape [n]
     const T *cap_rate;          // xi / eta rate BEFORE this update [n]
-    const double *s_other;      // [K] sum over the other loading of E[x]
+    const double *s_other;      // [K] sum over the other loading of E[x] ...
+    const double *s_other_part; // ... or (s_other_nb > 0) its per-block partials [s_other_nb, K], summed here:
+    int s_other_nb;             //     small problems skip the separate reduce launch (capi.hip fuse_sums)
     double cap_prior_rate;      // bp or dp
     T *shape, *rate;            // [n, K] in/out
     T *cap_rate_out;            // [n]

@@ -66,15 +66,32 @@ template <typename T> __device__ __forceinline__ double sum_strided(const T *__r
 template <typename T, int SRC>
 __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
 {
-    extern __shared__ double lds[];  // [rb*K] E, [rb*K] L, [K] column sums
+    extern __shared__ double lds[];  // [rb*K] E, [rb*K] L, [K] column sums, [K] sums of the other side
     const int K = a.K, KP = a.KP, rb = a.rows_per_block;
     double *sE = lds;
     double *sL = lds + (size_t)rb * K;
     double *sC = sL + (size_t)rb * K;
+    double *sS = sC + K;
     const int t = threadIdx.x;
     const int r = t / K, k = t - r * K;
     const bool lane_on = r < rb;
     if (t < K) sC[t] = 0.0;
+    if (SRC != SRC_NONE && a.s_other_nb > 0) {
+        // the other side's column sums from its per-block partials, in a fixed order that is the same
+        // in every block: thread (r, k) takes blocks r, r + rb, ...; then factor k's rb values in turn
+        double p = 0.0;
+        if (lane_on)
+            for (int b = r; b < a.s_other_nb; b += rb) p += a.s_other_part[(size_t)b * K + k];
+        if (lane_on) sE[r * K + k] = p;
+        __syncthreads();
+        if (t < K) {
+            double tot = 0.0;
+            for (int q = 0; q < rb; ++q) tot += sE[q * K + t];
+            sS[t] = tot;
+        }
+        __syncthreads();
+    }
+    const double s_other_k = (SRC != SRC_NONE && lane_on) ? (a.s_other_nb > 0 ? sS[k] : a.s_other[k]) : 0.0;
     const int groups = (a.n + rb - 1) / rb;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int row = grp * rb + r;
@@ -97,7 +114,7 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
                     acc = (double)a.dense[(size_t)row * K + k];
                 }
                 shape = a.prior_shape + acc;
-                rate = (double)a.cap_shape[row] / (double)a.cap_rate[row] + a.s_other[k];
+                rate = (double)a.cap_shape[row] / (double)a.cap_rate[row] + s_other_k;
                 a.shape[(size_t)row * K + k] = (T)shape;
                 a.rate[(size_t)row * K + k] = (T)rate;
                 shape = (double)(T)shape;  // tables follow the stored (rounded) parameters
@@ -419,7 +436,7 @@ static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 25
 
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st)
 {
-    const size_t lds = ((size_t)2 * a.rows_per_block * a.K + a.K) * sizeof(double);
+    const size_t lds = ((size_t)2 * a.rows_per_block * a.K + 2 * a.K) * sizeof(double);
     dim3 grid((unsigned)nblocks), block(256);
     if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE>), grid, block, lds, st, a);
     else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS>), grid, block, lds, st, a);

@@ -810,3 +810,29 @@ def test_library_rccl_one_rank_equals_plain_steps(amd, oracle):
         want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
                                              st.beta_shape, st.beta_rate)
         assert_allclose(shard.mean_negative_pois_llh(), want, rtol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fused_column_sums_and_mode_switches_match_oracle(amd, oracle, dtype, monkeypatch):
+    """Small problems skip the two column-sum reduce launches of an iteration: the update kernels
+    sum the other side's per-block partials themselves (default ordering only).  Switching between
+    the default ordering and the orderings that read the reduced sums (simultaneous, freeze_genes)
+    must bring those sums up to date; with the fusion off the results agree to round-off."""
+    X = synthetic_counts(700, 450, 0.07, seed=41)
+    K, a, c = 9, 0.3, 0.3
+    f32 = np.dtype(dtype) == np.float32
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=8)
+    seq = [{}, {}, {"simultaneous": True}, {}, {"freeze_genes": True}, {}, {"simultaneous": True}]
+    states = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("SCHPF_FUSE_SUMS", fuse)
+        ref = st.copy()
+        with load_engine(amd, X, K, dtype, ref, a, c, bp, dp) as eng:
+            for it, flags in enumerate(seq):
+                eng.step(**flags)
+                oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp, **flags)
+                compare_state(eng, ref, rtol=(2e-5 * (it + 1)) if f32 else 1e-11)
+            states[fuse] = [eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")]
+    for (s1, r1), (s0, r0) in zip(states["1"], states["0"]):
+        assert_allclose(s1, s0, rtol=1e-5 if f32 else 1e-13)
+        assert_allclose(r1, r0, rtol=1e-5 if f32 else 1e-13)
