@@ -80,8 +80,21 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
         // the other side's column sums from its per-block partials, in a fixed order that is the same
         // in every block: thread (r, k) takes blocks r, r + rb, ...; then factor k's rb values in turn
         double p = 0.0;
-        if (lane_on)
-            for (int b = r; b < a.s_other_nb; b += rb) p += a.s_other_part[(size_t)b * K + k];
+        if (lane_on) {   // eight loads in flight: the partials sit in L2, a rolled loop would pay one latency per term
+            const double *__restrict__ src = a.s_other_part + k;
+            const size_t st = (size_t)rb * K;
+            double q[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int b = r;
+            for (; b + 7 * rb < a.s_other_nb; b += 8 * rb) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)b * K + j * st];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q[j] += v[j];
+            }
+            for (; b < a.s_other_nb; b += rb) q[0] += src[(size_t)b * K];
+            p = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        }
         if (lane_on) sE[r * K + k] = p;
         __syncthreads();
         if (t < K) {
