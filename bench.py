@@ -184,7 +184,7 @@ def cpu_baseline(X, K, dtype):
          scatter-adds and rate updates (hpf_numba.py:24,54 parallel; :128,159 serial).  This is
          the stand-in for "the reference numba CPU path" (numba itself is not installable here) and
          is what `value` reports.  It needs 16 GB and minutes per iteration at C3, so it is timed
-         on TWO bounded row-subsamples (about 1/16 and 1/8 of the nonzeros); time is fitted as
+         on TWO bounded row-subsamples (about 1/8 and 1/4 of the nonzeros); time is fitted as
          alpha * nnz + gamma and extrapolated to the whole matrix; the two plain nnz-scalings are
          reported beside it as the spread.
     (ii) "fused OpenMP" (oracle/cavi_fused_impl.h): exp hoisted, no Xphi, parallel CSR + CSC
@@ -196,7 +196,7 @@ def cpu_baseline(X, K, dtype):
     N, G = X.shape
     nnz_full = X.nnz
     points = []
-    for frac_target in (1.25e8, 2.5e8):            # nnz*K element budget of a sample
+    for frac_target in (2.5e8, 5.0e8):             # nnz*K element budget of a sample (1/8 and 1/4 of C3)
         target_nnz = min(nnz_full, int(frac_target / K))
         rows = max(1, int(N * target_nnz / max(nnz_full, 1)))
         keep = X.row < rows
@@ -204,7 +204,7 @@ def cpu_baseline(X, K, dtype):
         bp, dp, st = _oracle_state(orc, Xs, K, dtype)
         x, row, col = Xs.data, Xs.row, Xs.col
         dt, iters = _time_iterations(
-            lambda: orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=cores), 6.0, 4)
+            lambda: orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=cores), 6.0, 3)
         points.append({"cells": rows, "nnz": int(Xs.nnz), "s_per_iter": dt, "iterations": iters,
                        "scaled_by_nnz_it_per_s": (1.0 / dt) * Xs.nnz / float(nnz_full)})
         if Xs.nnz == nnz_full:
