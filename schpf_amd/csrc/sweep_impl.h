@@ -623,27 +623,31 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                         xc[(i + 1) & 1][0] = EF::val(cn, 0); xc[(i + 1) & 1][1] = EF::val(cn, 1);
                         asm volatile("" : "+v"(n0), "+v"(n1), "+v"(xc[(i + 1) & 1][0]), "+v"(xc[(i + 1) & 1][1]));
                         const T x0 = (T)xc[i & 1][0], x1 = (T)xc[i & 1][1];
+                        // both normalisers first: two independent dot / reciprocal chains in flight
+                        // (measured -1 % f64, -3 % f32 against finishing nonzero A before starting B:
+                        // profiles/r02/ab_step_variants.log).  No test of the normaliser here: a
+                        // product-form s that underflowed (zero / denormal) makes the reciprocal inf,
+                        // and inf * b or 0 * inf poisons EVERY accumulator of every lane of the group
+                        // (inf or NaN) -- detected once, after the task, and the group is then redone by
+                        // the cold path.  A small but normal s is exact enough: its largest term is a
+                        // normal number.
                         const T s0 = group_dot<T, KL, LPC>(tm, bA);
-                        if (MODE == MODE_PHI) {
-                            // no test of the normaliser here: a product-form s that underflowed (zero /
-                            // denormal) makes the reciprocal inf, and inf * b or 0 * inf poisons EVERY
-                            // accumulator of every lane of the group (inf or NaN) -- detected once, after
-                            // the task, and the group is then redone by the cold path.  A small but
-                            // normal s is exact enough: its largest term is a normal number.
-                            const T q0 = fast_div(x0, s0);
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
-                        }
-                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
-                        // nothing moves across: row A' must be requested BEFORE nonzero B is computed
-                        __builtin_amdgcn_sched_barrier(0);
                         const T s1 = group_dot<T, KL, LPC>(tm, bB);
                         if (MODE == MODE_PHI) {
+                            const T q0 = fast_div(x0, s0);
                             const T q1 = fast_div(x1, s1);
 #pragma unroll
+                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
+                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
+                            // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
+                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
+                        } else {
+                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
+                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
                         }
-                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
                         if (MODE == MODE_LLH) {
                             if (LPC == 1) {
                                 if (x0 > T(0)) lacc.add((double)x0, (double)s0);

@@ -148,6 +148,45 @@ class _LossMonitor(object):
         return None
 
 
+class _EarlyUpload(object):
+    """Engine creation + upload of X on a helper thread while the caller initialises the model."""
+
+    def __init__(self, X, nfactors, dtype, device):
+        import threading
+        self._out = {}
+
+        def work():
+            eng = None
+            try:
+                eng = DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device)
+                import warnings
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    eng.upload(X)
+                self._out["engine"], self._out["warnings"] = eng, caught
+            except BaseException as exc:     # re-raised on the caller's thread
+                if eng is not None:
+                    eng.close()
+                self._out["error"] = exc
+        self._thread = threading.Thread(target=work, name="schpf-upload")
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if "error" in self._out:
+            raise self._out["error"]
+        import warnings
+        for w in self._out.get("warnings", ()):      # e.g. "values were rounded to float32"
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        return self._out["engine"]
+
+    def abandon(self):
+        self._thread.join()
+        eng = self._out.get("engine")
+        if eng is not None:
+            eng.close()
+
+
 class scHPF(BaseEstimator):
     """Single-cell hierarchical Poisson factorization (Levitin et al., MSB 2019).
 
@@ -305,7 +344,25 @@ class scHPF(BaseEstimator):
         nfactors, (ncells, ngenes) = self.nfactors, X.shape
         a, ap, c, cp = self.a, self.ap, self.c, self.cp
 
-        bp, dp, xi, eta, theta, beta = self._setup(X, freeze_genes, reinit)
+        if device is None:
+            import os
+            device = int(os.environ.get("SCHPF_DEVICE", "0"))
+        if devices is not None and len(devices) == 1:
+            device = int(devices[0])
+        model_dtype = np.dtype(self.dtype)
+        # The upload (validation, PCIe copy, both plans built on the device: ~0.1 s at 1e8 nonzeros)
+        # does not depend on the initialisation, and the initialisation (marginals for bp/dp, the
+        # uniform draws for the four Gammas: ~0.06 s) does not depend on the device: run them side by
+        # side.  The library calls release the GIL; NumPy's RNG is only touched on this thread.
+        early = None
+        if engine is None and not batched and not (devices is not None and len(devices) > 1):
+            early = _EarlyUpload(X, nfactors, model_dtype, device)
+        try:
+            bp, dp, xi, eta, theta, beta = self._setup(X, freeze_genes, reinit)
+        except BaseException:
+            if early is not None:
+                early.abandon()
+            raise
         # the hierarchical shapes are constants of the model (scHPF_.py:616-618)
         xi.vi_shape[:] = ap + nfactors * a
         if not freeze_genes:
@@ -319,30 +376,26 @@ class scHPF(BaseEstimator):
         # (scHPF_.py:639 vs :752-753); reproduced so iteration counts match.
         monitor = _LossMonitor(self.epsilon, self.better_than_n_ago, min_iter, loss_smoothing)
 
-        if device is None:
-            import os
-            device = int(os.environ.get("SCHPF_DEVICE", "0"))
-        model_dtype = np.dtype(self.dtype)
         if batched:
             return self._fit_minibatch(X, bp, dp, xi, eta, theta, beta, monitor, freeze_genes, reinit,
                                        loss_function, max_iter, check_freq, checkstep_function, verbose,
                                        batchsize, beta_theta_simultaneous, device)
         own_engine = engine is None
         sharded = own_engine and devices is not None and len(devices) > 1
-        if devices is not None and len(devices) == 1:
-            device = int(devices[0])
         if sharded:
             from .sharded import ThreadedShards
             import os
             eng = ThreadedShards(X, nfactors, model_dtype, devices,      # uploads its row blocks itself
                                  comm=os.environ.get("SCHPF_SHARD_COMM", "rccl"))
+        elif early is not None:
+            eng = early.result()                     # the engine with X uploaded (raises what the upload raised)
         else:
             eng = DeviceCAVI(ncells, ngenes, nfactors, dtype=model_dtype, device=device) if own_engine else engine
         if not own_engine and ((eng.ncells, eng.ngenes, eng.nfactors) != (ncells, ngenes, nfactors)
                                or eng.dtype != model_dtype or eng.nnz != X.data.shape[0]):
             raise ValueError("engine was built for a different matrix, nfactors or dtype")
         try:
-            if own_engine and not sharded:
+            if own_engine and not sharded and early is None:
                 eng.upload(X)
             eng.set_hypers(a, c, bp, dp)
             for name, g in (("xi", xi), ("theta", theta), ("eta", eta), ("beta", beta)):
