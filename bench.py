@@ -334,7 +334,10 @@ def main():
     init_engine(eng, X, K, dtype)
     upload_s = time.perf_counter() - t_up
     nnz_local = X.nnz
-    use_graph = (args.graph or args.config == "c2") and not sharded
+    # one library call for all K timed iterations: a hipGraph replay on one GPU (launch-bound configs),
+    # and always for sharded runs with the library's collective (the launch queue stays full: -12 % per
+    # iteration against one call per iteration; SCHPF_GRAPH_SHARDED=1 also captures them in a graph)
+    use_graph = ((args.graph or args.config == "c2") and not sharded) or (sharded and args.comm == "library")
     if sharded and args.comm == "library":
         from schpf_amd.sharded import NativeShard
         # rank 0's communicator id reaches the other ranks through the process group that is there anyway
@@ -366,13 +369,14 @@ def main():
     eng.init_phi_device(12345)          # t = 0 responsibilities (device generator)
     for _ in range(args.warmup):
         step()
+    many = getattr(drv, "steps", None) if sharded else eng.steps   # sharded: a graph only with SCHPF_GRAPH_SHARDED=1
     if use_graph:
-        eng.steps(args.steps)           # untimed: captures the K-iteration graph the timed call replays
+        many(args.steps)                # untimed: captures the K-iteration graph the timed call replays
     loss_start = loss_fn()
     if use_graph:
         fence()
         t0 = time.perf_counter()
-        eng.steps(args.steps)           # EXACTLY K iterations, one hipGraph launch
+        many(args.steps)                # EXACTLY K iterations, one library call (one hipGraph launch)
         fence()
         elapsed = time.perf_counter() - t0
         eng.profile(True)               # kernel times for the roofline: a second, eager pass of K iterations
@@ -430,8 +434,10 @@ def main():
             "parallelism": ("cells row-sharded x%d, one RCCL all-reduce of G*K+K per iteration (%s)"
                             % (world, "issued by the library" if args.comm == "library" else "torch.distributed"))
                            if world > 1 else "single GPU",
-            "launch": "one hipGraph of %d iterations (schpf_steps), +%d untimed iterations to capture it"
-                      % (args.steps, args.steps) if use_graph else "one library call per iteration, eager launches",
+            "launch": ("one library call for the %d timed iterations (%s), after %d untimed iterations of the same call"
+                       % (args.steps, "schpf_steps_sharded; a hipGraph only with SCHPF_GRAPH_SHARDED=1" if sharded
+                          else "schpf_steps: one hipGraph replay", args.steps))
+                      if use_graph else "one library call per iteration, eager launches",
             "plan": info,
         },
         "roofline": {

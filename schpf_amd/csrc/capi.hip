@@ -372,7 +372,8 @@ template <typename T> struct Engine final : schpf_ctx {
         const unsigned base = (flags_ | SCHPF_SHARDED) & ~(unsigned)(SCHPF_LOCAL_GENE | SCHPF_LOCAL_CELL);
         const bool freeze = flags_ & SCHPF_FREEZE_GENES;
         const int dt = sizeof(T) == 4 ? 7 : 8;   // ncclFloat32 / ncclFloat64
-        for (int i = 0; i < n; ++i) {
+        auto iterate = [&](int count) {
+        for (int i = 0; i < count; ++i) {
             if (freeze) { step_local(base); step_finish(base); continue; }   // nothing to exchange
             step_local(base | SCHPF_LOCAL_GENE);
             HIPCHK(hipEventRecord(ev_packed, stream));
@@ -383,6 +384,37 @@ template <typename T> struct Engine final : schpf_ctx {
             HIPCHK(hipStreamWaitEvent(stream, ev_reduced, 0));
             step_finish(base);
         }
+        };
+        // Opt-in (SCHPF_GRAPH_SHARDED=1): the stretch as one hipGraph -- both streams, the events between
+        // them and the RCCL all-reduce captured (RCCL supports stream capture).  Off by default: it could
+        // only be tried with a one-rank communicator here, and every rank must replay the same graph.
+        int done = 0;
+        const bool graphable = env_int("SCHPF_GRAPH_SHARDED", 0) && !prof.on && stream != nullptr &&
+                               pending_init == 0 && eager_since_upload && !dirty_theta && !dirty_beta && !freeze;
+        if (graphable && n >= 2) {
+            const int even = n & ~1;
+            if (!graph_exec || graph_flags != (base | 0x80000000u) || graph_n != even) {
+                drop_graph();
+                hipGraph_t graph = nullptr;
+                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    iterate(even);
+                } catch (...) {
+                    (void)hipStreamEndCapture(stream, &graph);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    throw;
+                }
+                HIPCHK(hipStreamEndCapture(stream, &graph));
+                const hipError_t e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                HIPCHK(e);
+                graph_flags = base | 0x80000000u;
+                graph_n = even;
+            }
+            HIPCHK(hipGraphLaunch(graph_exec, stream));
+            done = even;
+        }
+        iterate(n - done);
         if (n > 0) eager_since_upload = true;
     }
 
@@ -1067,8 +1099,8 @@ template <typename T> struct Engine final : schpf_ctx {
                                                0, stream));
             sums_stale = false;
         }
-        // sharded: the all-reduced sum_i E[theta_ik] (old theta) is the tail of the exchange buffer
-        if (sharded) widen_tail();
+        // sharded: the all-reduced sum_i E[theta_ik] (old theta) is the tail of the exchange buffer; the
+        // gene update reads it from there (s_other_t)
         auto gene_update = [&] {
         if (!freeze) {  // gene block, scHPF_.py:697-704 (or :668-673 + :682-685)
             schpf::UpdateArgs<T> u{};
@@ -1079,6 +1111,7 @@ template <typename T> struct Engine final : schpf_ctx {
             u.prior_shape = c;
             u.cap_shape = eta_s.as<T>(); u.cap_rate = eta_r.as<T>();
             u.s_other = s_theta.as<double>();
+            if (sharded) u.s_other_t = exchange_buf.as<T>() + (size_t)G * K;
             if (fuse) { u.s_other_part = colpart_cell.as<double>(); u.s_other_nb = upd_blocks(N); }
             u.cap_prior_rate = dp;
             u.shape = be_s.as<T>(); u.rate = be_r.as<T>(); u.cap_rate_out = eta_r.as<T>();
@@ -1124,7 +1157,6 @@ template <typename T> struct Engine final : schpf_ctx {
         tm.stop();
     }
 
-    void widen_tail();  // exchange tail (T) -> s_theta (double)
 
     void loss_terms(double *llh, double *gl, int64_t *nnz_out) override
     {
@@ -1175,19 +1207,6 @@ template <typename T> struct Engine final : schpf_ctx {
         }
     }
 };
-
-// tiny widening kernel for the sharded path: exchange tail (T) -> double[K]
-template <typename T> __global__ void widen_kernel(const T *__restrict__ in, int n, double *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)in[i];
-}
-template <typename T> void Engine<T>::widen_tail()
-{
-    hipLaunchKernelGGL((widen_kernel<T>), dim3(1), dim3(256), 0, stream, exchange_buf.as<T>() + (size_t)G * K, K,
-                       s_theta.as<double>());
-    HIPCHK(hipGetLastError());
-}
 
 // ------------------------------------------------------------- stateless helpers
 struct TempStream {

@@ -55,6 +55,7 @@ template <typename T> struct UpdateArgs {
     const T *cap_shape;         // xi / eta shape [n]
     const T *cap_rate;          // xi / eta rate BEFORE this update [n]
     const double *s_other;      // [K] sum over the other loading of E[x] ...
+    const T *s_other_t;         // ... or (non-null) the same in the model dtype: the all-reduced tail of the exchange buffer
     const double *s_other_part; // ... or (s_other_nb > 0) its per-block partials [s_other_nb, K], summed here:
     int s_other_nb;             //     small problems skip the separate reduce launch (capi.hip fuse_sums)
     double cap_prior_rate;      // bp or dp

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
         }
         __syncthreads();
     }
-    const double s_other_k = (SRC != SRC_NONE && lane_on) ? (a.s_other_nb > 0 ? sS[k] : a.s_other[k]) : 0.0;
+    const double s_other_k = (SRC != SRC_NONE && lane_on)
+                                 ? (a.s_other_nb > 0 ? sS[k] : (a.s_other_t ? (double)a.s_other_t[k] : a.s_other[k]))
+                                 : 0.0;
     const int groups = (a.n + rb - 1) / rb;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int row = grp * rb + r;
