@@ -330,6 +330,8 @@ def main():
 
     # the engine enqueues on a stream of its own; ShardedCAVI orders the collective with it
     eng = DeviceCAVI(n_local, G, K, dtype=dtype, device=local_rank)
+    if sharded:
+        eng.hint_sharded()
     t_up = time.perf_counter()
     init_engine(eng, X, K, dtype)
     upload_s = time.perf_counter() - t_up

@@ -176,6 +176,10 @@ int schpf_synchronize(schpf_ctx *ctx);
  * n x [schpf_step_local(gene side) -> all-reduce of the exchange buffer on the communicator's own
  * stream, under the cell-side sweep -> schpf_step_finish]; freeze_genes needs no exchange.
  * schpf_loss_terms_all = schpf_loss_terms summed over the ranks. */
+/* Before schpf_upload_coo, optional: tell the context that its iterations will be sharded ones (the two
+ * sweeps then run as two launches, and the plans of a small row block are cut into tasks that fill the
+ * GPU once per launch instead of once per pair of launches). */
+int schpf_hint_sharded(schpf_ctx *ctx, int on);
 int schpf_comm_unique_id(void *out128);
 int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int world);
 int schpf_comm_destroy(schpf_ctx *ctx);

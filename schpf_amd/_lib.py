@@ -49,6 +49,7 @@ SIGNATURES = {
     "schpf_step_finish": [_vp, ctypes.c_uint],
     "schpf_loss_terms": [_vp, _dblp, _dblp, _i64p],
     "schpf_synchronize": [_vp],
+    "schpf_hint_sharded": [_vp, _int],
     "schpf_comm_unique_id": [_vp],
     "schpf_comm_init": [_vp, _vp, _int, _int],
     "schpf_comm_destroy": [_vp],

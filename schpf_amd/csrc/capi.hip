@@ -221,6 +221,7 @@ struct schpf_ctx {
     virtual void step_finish(unsigned flags) = 0;
     virtual void steps(unsigned flags, int n) = 0;
     virtual void hypers_changed() = 0;
+    virtual void hint_sharded(int on) = 0;
     virtual void steps_sharded(unsigned flags, int n) = 0;
     virtual void loss_terms_all(double *llh, double *gl, int64_t *nnz) = 0;
     // cells sharded over GPUs: this rank's RCCL communicator and the stream its collectives run on
@@ -289,6 +290,7 @@ template <typename T> struct Engine final : schpf_ctx {
     // two reduce launches of an iteration are skipped; s_theta / s_beta are then brought up to date
     // only when a path that reads them comes along (sums_stale)
     bool sums_stale = false;
+    bool expect_sharded = false;        // schpf_hint_sharded: the sweeps will run as two launches
     static constexpr int UPD_BLOCKS = 2048;
     static constexpr size_t TABLE_PAD = 256 * 1024;
 
@@ -316,7 +318,8 @@ template <typename T> struct Engine final : schpf_ctx {
         colpart_gene.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
         scalars.alloc(8 * sizeof(double), true, stream);
     }
-    void hypers_changed() override { drop_graph(); }   // a, c, bp, dp are kernel arguments of the captured launches
+    void hypers_changed() override { drop_graph(); }
+    void hint_sharded(int on) override { expect_sharded = on != 0; }   // a, c, bp, dp are kernel arguments of the captured launches
     void drop_graph()
     {
         if (graph_exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -660,6 +663,16 @@ template <typename T> struct Engine final : schpf_ctx {
         if (dflt >= 1024 && blocks < 64) dflt /= 2;
         sh.target_tasks = env_int("SCHPF_TASKS", dflt);
         sh.target_tasks = env_int(gene_side ? "SCHPF_TASKS_GENE" : "SCHPF_TASKS_CELL", sh.target_tasks);
+        // workgroups in flight: one 1024-thread (152 KiB) workgroup per CU, two of the smaller ones; both
+        // orientations share a launch unless the iteration is sharded (two launches, schpf_hint_sharded)
+        int n_cu = 256;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                n_cu = prop.multiProcessorCount;
+        }
+        const int per_launch = n_cu * (wpb >= 12 ? 1 : 2);
+        sh.slots = env_int("SCHPF_TASK_ROUNDING", 1) ? (expect_sharded ? per_launch : per_launch / 2) : 0;
         return sh;
     }
 
@@ -1477,6 +1490,7 @@ int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int worl
     CTX_CALL(ctx->comm_init(unique_id128, rank, world));
 }
 int schpf_comm_destroy(schpf_ctx *ctx) { CTX_CALL(ctx->comm_destroy()); }
+int schpf_hint_sharded(schpf_ctx *ctx, int on) { CTX_CALL(ctx->hint_sharded(on)); }
 int schpf_steps_sharded(schpf_ctx *ctx, unsigned flags, int n)
 {
     if (n < 0) return fail("n must be >= 0");

@@ -392,6 +392,17 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     int64_t wpt = 1;
     if (target_tasks > 0) wpt = std::max<int64_t>(1, (int64_t)W * P.n_blocks / target_tasks);
     wpt = std::min<int64_t>(wpt, W);
+    // Small problems: a launch of slightly more workgroups than the GPU runs at once takes two rounds
+    // where one would do (an 1/8 shard of C3: 275 tasks of 2 windows on 256 CUs = 4 window-times;
+    // 175 tasks of 3 windows = 3).  With `slots` = workgroups this orientation can have in flight,
+    // between one and two rounds' worth of tasks are regrouped into one round.
+    if (shape.slots > 0) {
+        const int64_t tasks = ((W + wpt - 1) / wpt) * P.n_blocks;
+        if (tasks > shape.slots && tasks < 2 * (int64_t)shape.slots && P.n_blocks <= shape.slots) {
+            const int64_t ranges = std::max<int64_t>(1, shape.slots / P.n_blocks);
+            wpt = std::min<int64_t>(W, (W + ranges - 1) / ranges);
+        }
+    }
     P.windows_per_task = (int)wpt;
     const int n_ranges = (int)((W + wpt - 1) / wpt);
     P.n_tasks = (int64_t)n_ranges * P.n_blocks;

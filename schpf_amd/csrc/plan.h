@@ -164,6 +164,7 @@ struct TilePlanHost {
 struct TileShape {
     int lpc = 1, waves_per_block = 16, win_rows = 1, target_tasks = 0, row_slots = 1;
     int ring = 1, slot_bytes = 0;
+    int slots = 0;          // workgroups of this orientation the GPU runs at once (0: unknown); see tile_plan_begin
     bool bank_order = true, allow_packed = true;
 };
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,

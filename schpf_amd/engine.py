@@ -175,6 +175,10 @@ class DeviceCAVI(object):
         _lib.check(_lib.load().schpf_comm_unique_id(buf))
         return buf.raw
 
+    def hint_sharded(self, on=True):
+        """Call before upload() when the engine will run sharded iterations (two sweep launches)."""
+        _lib.check(self._lib.schpf_hint_sharded(self._h, int(bool(on))))
+
     def comm_init(self, unique_id, rank, world):
         """Join the communicator (collective: returns once all `world` ranks have called it)."""
         if len(unique_id) != 128:

@@ -145,6 +145,7 @@ class ThreadedShards(object):
             sub, keep = take_rows(X, lo, hi)
             self.keep[rank] = keep
             eng = DeviceCAVI(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
+            eng.hint_sharded()
             eng.upload(sub)
             if uid is not None:
                 eng.comm_init(uid, rank, self.world)     # collective: all threads arrive here
