@@ -168,15 +168,9 @@ struct Rccl {
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
-Rccl &rccl()
+Rccl load_rccl()
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) {
-        if (!r.handle) throw std::runtime_error("RCCL is not available in this process");
-        return r;
-    }
-    tried = true;
+    Rccl r;
     const char *env = getenv("SCHPF_RCCL_PATH");
     const char *names[] = {"librccl.so", "librccl.so.1", env && *env ? env : nullptr, "librccl.so", "librccl.so.1",
                            "/opt/rocm/lib/librccl.so"};
@@ -187,7 +181,7 @@ Rccl &rccl()
     if (!r.handle) throw std::runtime_error("cannot load RCCL (librccl.so): set SCHPF_RCCL_PATH");
     auto sym = [&](const char *n) {
         void *p = dlsym(r.handle, n);
-        if (!p) { r.handle = nullptr; throw std::runtime_error(std::string("RCCL lacks ") + n); }
+        if (!p) throw std::runtime_error(std::string("RCCL lacks ") + n);
         return p;
     };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
@@ -195,6 +189,11 @@ Rccl &rccl()
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    return r;
+}
+Rccl &rccl()
+{
+    static Rccl r = load_rccl();   // thread-safe; a failed load throws and is tried again by the next caller
     return r;
 }
 #define RCCLCHK(expr)                                                                                     \
