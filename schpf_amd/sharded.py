@@ -107,6 +107,12 @@ class ShardedCAVI(object):
         return -(llh - gl) / nnz
 
 
+# What ThreadedShards builds a shard's engine with when its caller passes nothing: None = DeviceCAVI.
+# A hook for the CPU test of the class (tests/test_sharded_cpu.py), not a fallback: the stand-in it
+# injects is test infrastructure.
+ENGINE_FACTORY = None
+
+
 class ThreadedShards(object):
     """One process, one host thread per GPU: the cells of X row-sharded over `devices`, every
     shard a DeviceCAVI on its device, all of them ranks of one RCCL communicator that lives
@@ -119,12 +125,15 @@ class ThreadedShards(object):
     concurrently -- which the collective needs: every rank must enqueue its all-reduce.
     """
 
-    def __init__(self, X, nfactors, dtype, devices, comm="rccl"):
+    def __init__(self, X, nfactors, dtype, devices, comm="rccl", engine_factory=None):
         """comm="rccl": the product path.  comm="emulated" (tests on a one-GPU box, where RCCL
         refuses two ranks on one device): no communicator; the all-reduce is played by adding the
-        shards' exchange buffers through torch views -- same packing, same update kernels."""
+        shards' exchange buffers through torch views -- same packing, same update kernels.
+        engine_factory: what builds a shard's engine (default DeviceCAVI; the CPU test of this
+        class injects a stand-in with the same surface, see ENGINE_FACTORY)."""
         from concurrent.futures import ThreadPoolExecutor
         from .engine import DeviceCAVI
+        make_engine = engine_factory or ENGINE_FACTORY or DeviceCAVI
         if not hasattr(X, "row"):
             X = X.tocoo()
         self.devices = list(devices)
@@ -144,7 +153,7 @@ class ThreadedShards(object):
             lo, hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
             sub, keep = take_rows(X, lo, hi)
             self.keep[rank] = keep
-            eng = DeviceCAVI(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
+            eng = make_engine(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
             eng.hint_sharded()
             eng.upload(sub)
             if uid is not None:
@@ -152,7 +161,8 @@ class ThreadedShards(object):
             return eng
         self.engines = self._each(build)
         if comm != "rccl":
-            self._views = [exchange_tensor_of(e, d) for e, d in zip(self.engines, self.devices)]
+            self._views = [e.exchange if hasattr(e, "exchange") else exchange_tensor_of(e, d)
+                           for e, d in zip(self.engines, self.devices)]
 
     def _each(self, fn):
         return list(self._pool.map(fn, range(self.world)))
@@ -200,8 +210,9 @@ class ThreadedShards(object):
                     total += v.to(total.device)
                 for v in self._views:
                     v.copy_(total.to(v.device))
-                import torch
-                torch.cuda.synchronize()
+                if total.is_cuda:
+                    import torch
+                    torch.cuda.synchronize()
                 for e in self.engines:
                     e.step_local(simultaneous=simultaneous, side="cell")
             else:

@@ -83,3 +83,28 @@ class OracleEngine(object):
         llh = orc.compute_pois_llh(X.data, X.row, X.col, ths, thr, bes, ber).astype(np.float64)
         gl = gammaln(X.data + 1.0)
         return float((llh + gl).sum()), float(gl.sum()), int(X.nnz)
+
+
+class OracleShardEngine(OracleEngine):
+    """The stand-in with DeviceCAVI's constructor and life cycle (create, hint, upload, close), so
+    that schpf_amd.sharded.ThreadedShards -- and through it scHPF.fit(X, devices=[...]) -- can be
+    driven on a box without a GPU."""
+
+    def __init__(self, ncells, ngenes, nfactors, dtype=np.float64, device=0):
+        self._shape = (int(ncells), int(ngenes))
+        self._k, self._dt = int(nfactors), np.dtype(dtype)
+        self.nnz = 0
+
+    def hint_sharded(self, on=True):
+        pass
+
+    def upload(self, X):
+        assert tuple(X.shape) == self._shape
+        OracleEngine.__init__(self, X, self._k, self._dt)
+        self.nnz = int(X.nnz)
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        pass

@@ -104,3 +104,36 @@ def test_two_ranks_reproduce_the_unsharded_oracle(tmp_path, oracle, flags, dtype
         assert_allclose(p["eta_r"], st.eta_rate, rtol=tol)
         assert_allclose(p["losses"], want_losses, rtol=1e-5 if dtype == np.float32 else 1e-11)
     assert np.array_equal(parts[0]["bes"], parts[1]["bes"])
+
+
+@pytest.mark.parametrize("kw", [{}, {"beta_theta_simultaneous": True}])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fit_over_devices_through_the_estimator(oracle, monkeypatch, kw, dtype):
+    """scHPF.fit(X, devices=[0, 1]) end to end on CPU: the estimator's loop, ThreadedShards'
+    partition / scatter / gather of the four Gammas, the per-stretch calls and the loss -- with
+    oracle-backed stand-in engines in place of DeviceCAVI and the all-reduce summed on the host.
+    Must reproduce the unsharded restatement of the reference's fit (same seed, same stop)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _oracle_engine import OracleShardEngine
+    import schpf_amd.sharded as sharded
+    from schpf import scHPF
+    monkeypatch.setattr(sharded, "ENGINE_FACTORY", OracleShardEngine)
+    monkeypatch.setenv("SCHPF_SHARD_COMM", "emulated")
+    X = synthetic_counts(120, 90, 0.15, seed=9)
+    K = 4
+    np.random.seed(5)
+    want = oracle.oracle_fit(X, K, dtype=dtype, max_iter=25, simultaneous=bool(kw))
+    np.random.seed(5)
+    model = scHPF(K, dtype=dtype, max_iter=25, verbose=False)
+    model.fit(X, devices=[0, 1], **kw)
+    f32 = np.dtype(dtype) == np.float32
+    assert model.bp == want["bp"] and model.dp == want["dp"]
+    assert len(model.loss) == len(want["loss"])
+    assert_allclose(model.loss, want["loss"], rtol=1e-4 if f32 else 1e-10)
+    st = want["state"]
+    for name in ("xi", "theta", "eta", "beta"):
+        got = getattr(model, name)
+        assert got.vi_shape.shape == getattr(st, name + "_shape").shape
+        assert_allclose(got.vi_shape, getattr(st, name + "_shape"), rtol=5e-3 if f32 else 1e-8, err_msg=name)
+        assert_allclose(got.vi_rate, getattr(st, name + "_rate"), rtol=5e-3 if f32 else 1e-8, err_msg=name)
