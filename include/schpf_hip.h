@@ -230,7 +230,8 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
  * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task}.
  * ring <= 1: window schedule with win_rows rows per window; ring >= 3: ring schedule with `ring`
  * slots of slot_bytes (a multiple of 1024 * waves_per_block; table rows are 160 bytes here) -- the
- * hook then also checks that every entry of an epoch points into a slot readable in that epoch. */
+ * hook then also checks that every entry of an epoch points into a slot readable in that epoch;
+ * ring <= -2: the half-window schedule with -ring slots of slot_bytes (a multiple of 16). */
 int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                             int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
                             int target_tasks, int ring, int slot_bytes, int32_t *out_major,

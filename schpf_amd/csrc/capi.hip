@@ -599,6 +599,13 @@ template <typename T> struct Engine final : schpf_ctx {
     // two workgroups per CU) until there are.  Measured on a 1/8 shard of C3 and on C2
     // (SCHPF_MIN_PAIRS = 768 / 256 / 128 / 64): the large workgroup wins well below one task per
     // CU, because both orientations share a launch and small windows cost padding and partials.
+    int n_cu() const
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            return prop.multiProcessorCount;
+        return 256;
+    }
     schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false) const
     {
         int wpb = env_int("SCHPF_WPB", 0);
@@ -649,10 +656,37 @@ template <typename T> struct Engine final : schpf_ctx {
                 sh.win_rows = (int)sub_rows;
             }
         }
+        // Half-window schedule (plan.h): the window's LDS cut into two slots, refilled at the epoch boundary
+        // by the window kernel itself.  Chosen where it was measured to pay (BASELINE C3: -3 % sweep time in
+        // float64, -2 % in float32; profiles/r02/explore_half_window.log): rows with many nonzeros per
+        // half window (the lock-step loss is what it removes; with ~3 per half window, C5, the second
+        // barrier per window costs more: +2 %) on a problem with many (block, window) pairs (it loses
+        // 2-8 % on the one-round launches of C2 and of a 1/8 shard).  SCHPF_HALF = 0 / slots overrides.
+        {
+            const int half_env = env_int("SCHPF_HALF", -1);
+            int n_slots = half_env >= 2 ? half_env : 0;
+            if (half_env < 0 && sh.ring <= 1) {
+                const int64_t half_rows = ((int64_t)lds_kb * 512 - 64) / (int64_t)row_bytes;
+                const double per_row = (double)nnz / std::max(1, n_major) * (double)half_rows / std::max(1, n_minor);
+                const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
+                const int64_t windows = ((int64_t)n_minor + sh.win_rows - 1) / sh.win_rows;
+                if (half_rows >= 1 && per_row >= 16.0 && blocks * windows >= 1024) n_slots = 2;
+            }
+            if (n_slots >= 2 && sh.ring <= 1) {
+                const int slot_bytes = (int)((size_t)lds_kb * 1024 / (size_t)n_slots / 16 * 16);
+                const int64_t sub_rows = ((int64_t)slot_bytes - 64) / (int64_t)row_bytes;
+                if (sub_rows >= 1) {
+                    sh.ring = n_slots;
+                    sh.sync_stage = 1;
+                    sh.slot_bytes = slot_bytes;
+                    sh.win_rows = (int)sub_rows;
+                }
+            }
+        }
         // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
         // there are few (block, window) pairs (1/8 shard of C3: 1024 -> 256 tasks is 10 % faster:
         // fewer partial rows to write and to sum, no ragged second round)
-        const int64_t lds_rows = sh.ring > 1 ? (int64_t)sh.win_rows * (sh.ring - 1) : sh.win_rows;
+        const int64_t lds_rows = sh.ring > 1 ? (int64_t)sh.win_rows * (sh.ring - (sh.sync_stage == 1 ? 0 : 1)) : sh.win_rows;
         const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
         const int64_t windows = ((int64_t)n_minor + lds_rows - 1) / lds_rows;
         // ... and half as many for an orientation with few blocks (the gene side of C3: 40 blocks of 512
@@ -664,13 +698,7 @@ template <typename T> struct Engine final : schpf_ctx {
         sh.target_tasks = env_int(gene_side ? "SCHPF_TASKS_GENE" : "SCHPF_TASKS_CELL", sh.target_tasks);
         // workgroups in flight: one 1024-thread (152 KiB) workgroup per CU, two of the smaller ones; both
         // orientations share a launch unless the iteration is sharded (two launches, schpf_hint_sharded)
-        int n_cu = 256;
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-                n_cu = prop.multiProcessorCount;
-        }
-        const int per_launch = n_cu * (wpb >= 12 ? 1 : 2);
+        const int per_launch = n_cu() * (wpb >= 12 ? 1 : 2);
         sh.slots = env_int("SCHPF_TASK_ROUNDING", 1) ? (expect_sharded ? per_launch : per_launch / 2) : 0;
         return sh;
     }
@@ -711,14 +739,26 @@ template <typename T> struct Engine final : schpf_ctx {
         if (env_int("SCHPF_DUAL", 1) && tcell.threads == tgene.threads && tcell.packed == tgene.packed) {
             const auto &hc = tcell.host, &hg = tgene.host;
             std::vector<int32_t> ord;
-            ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
-            size_t i = 0, j = 0;   // merge of two lists already sorted by decreasing work
-            while (i < hc.task_order.size() || j < hg.task_order.size()) {
-                const bool take_cell = j >= hg.task_order.size() ||
-                    (i < hc.task_order.size() &&
-                     hc.task_work[(size_t)hc.task_order[i]] >= hg.task_work[(size_t)hg.task_order[j]]);
-                if (take_cell) ord.push_back(hc.task_order[i++]);
-                else ord.push_back(~hg.task_order[j++]);
+            const int n_xcd = env_int("SCHPF_XCD", 1);
+            if (n_xcd > 1 && n_cu() % n_xcd == 0) {
+                // same-range tasks on one XCD at a time (plan.h xcd_launch_order); one 152 KiB workgroup per
+                // compute unit, two of the smaller ones.  Opt-in (SCHPF_XCD=8): it does what it is meant to --
+                // L2 hits of the sweep 47 % -> 83 % at the C5 share, 49 % -> 54 % at C3 -- and the sweep is no
+                // faster for it (C5 2.48 vs 2.42 ms, C3 f32 +10 %: coarser tail): the window copy is bound by
+                // the CU's own LDS-DMA rate, not by where the rows come from (tools/micro/stage_bench.hip)
+                const schpf::TilePlanHost *both[2] = {&hc, &hg};
+                const int per_cu = tcell.lds_bytes > 80 * 1024 ? 1 : 2;
+                schpf::xcd_launch_order(both, 2, n_xcd, n_cu() / n_xcd * per_cu, ord);
+            } else {
+                ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
+                size_t i = 0, j = 0;   // merge of two lists already sorted by decreasing work
+                while (i < hc.task_order.size() || j < hg.task_order.size()) {
+                    const bool take_cell = j >= hg.task_order.size() ||
+                        (i < hc.task_order.size() &&
+                         hc.task_work[(size_t)hc.task_order[i]] >= hg.task_work[(size_t)hg.task_order[j]]);
+                    if (take_cell) ord.push_back(hc.task_order[i++]);
+                    else ord.push_back(~hg.task_order[j++]);
+                }
             }
             dual_slots = (int64_t)ord.size();
             if (dual_slots > 0) { upload(dual_order, ord, stream); HIPCHK(hipStreamSynchronize(stream)); }
@@ -953,7 +993,7 @@ template <typename T> struct Engine final : schpf_ctx {
         a.wave_out = wave_out.as<double>();
         a.K = K; a.n_minor = n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
         a.wpb = td.host.wpb;
-        a.ring = td.host.ring; a.slot_bytes = td.host.slot16 * 16;
+        a.ring = td.host.ring; a.slot_bytes = td.host.slot16 * 16; a.sync_stage = td.host.sync_stage;
         return a;
     }
 
@@ -1621,7 +1661,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         schpf::TileShape sh;
         sh.lpc = lpc; sh.waves_per_block = waves_per_block; sh.win_rows = win_rows; sh.target_tasks = target_tasks;
         sh.row_slots = 10;   // 160-byte table rows
-        sh.ring = ring; sh.slot_bytes = slot_bytes;
+        sh.ring = ring < 0 ? -ring : ring; sh.sync_stage = ring < 0 ? 1 : 0; sh.slot_bytes = slot_bytes;
         sh.allow_packed = getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true;
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, false, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
@@ -1632,7 +1672,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                 int64_t off = P.task_wave_off[(size_t)t * wpb + v];
                 for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                     const int steps = P.steps[((size_t)b * wpb + v) * W + w];
-                    if (P.ring > 1 && steps != P.steps[((size_t)b * wpb) * W + w])
+                    if (P.ring > 1 && !P.sync_stage && steps != P.steps[((size_t)b * wpb) * W + w])
                         throw std::logic_error("ring plan: the waves of a block disagree on an epoch's steps");
                     for (int p = 0; p < steps; ++p)
                         for (int grp = 0; grp < gpw; ++grp)
@@ -1653,8 +1693,8 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                                     const int slot = (int)(off16 / (uint32_t)P.slot16);
                                     const int r = (int)((off16 - (uint32_t)slot * P.slot16) / (uint32_t)P.row_slots);
                                     const int ahead = (slot - w % P.ring + P.ring) % P.ring;
-                                    // readable in epoch w: sub-windows w .. w + ring - 2, inside the task
-                                    if (slot >= P.ring || ahead > P.ring - 2 || w + ahead >= P.task_w1[(size_t)t])
+                                    // readable in epoch w: sub-windows w .. w + look, inside the task
+                                    if (slot >= P.ring || ahead > P.look || w + ahead >= P.task_w1[(size_t)t])
                                         throw std::logic_error("ring plan: an entry points outside the readable slots");
                                     if (f == 0.0f && off16 != (uint32_t)(w % P.ring) * (uint32_t)P.slot16)
                                         throw std::logic_error("ring plan: padding must point at the epoch's own slot");

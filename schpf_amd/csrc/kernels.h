@@ -40,6 +40,7 @@ template <typename T> struct TileArgs {
     double *wave_out;              // [n_tasks * wpb] (LLH)
     int K, n_minor, n_windows, win_rows, wpb;
     int ring, slot_bytes;          // ring mode (plan.h): slots in the LDS ring (<= 1: window mode), bytes per slot
+    int sync_stage;                // ring mode: half-window schedule (slots refilled at the epoch boundary)
     uint64_t seed;                 // MODE_RANDOM
     int major_is_cell;
 };

@@ -357,10 +357,15 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     P.row_slots = shape.row_slots;
     int win_rows = shape.win_rows;
     if (shape.ring > 1) {
-        if (shape.ring < 3) throw std::invalid_argument("a ring needs at least 3 slots");
-        if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % (1024 * waves_per_block))
-            throw std::invalid_argument("slot_bytes must hold a row and be a multiple of 1 KiB per wave");
+        if (shape.sync_stage < 0 || shape.sync_stage > 1) throw std::invalid_argument("sync_stage is 0 or 1");
+        if (shape.ring < (shape.sync_stage == 1 ? 2 : 3)) throw std::invalid_argument("too few ring slots");
+        if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % 16 ||
+            (!shape.sync_stage && shape.slot_bytes % (1024 * waves_per_block)))
+            throw std::invalid_argument("slot_bytes must hold a row (and, for the asynchronous ring, be a multiple "
+                                        "of 1 KiB per wave)");
         P.ring = shape.ring;
+        P.sync_stage = shape.sync_stage;
+        P.look = shape.sync_stage == 1 ? shape.ring - 1 : shape.ring - 2;
         P.slot16 = shape.slot_bytes / 16;
         win_rows = (P.slot16 - 4) / shape.row_slots;   // the last 64 bytes of a slot stay free (kernel: counters)
     }
@@ -426,6 +431,57 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
             if (row >= 0) P.pfirst[(size_t)row] = (int32_t)(b * gpb + g);
         }
     P.steps.assign((size_t)P.n_blocks * P.wpb * W, 0);
+}
+
+void xcd_launch_order(const TilePlanHost *const *plans, int n_plans, int n_xcd, int bundle, std::vector<int32_t> &order)
+{
+    struct Item { int32_t code; int64_t work; int64_t key; };
+    std::vector<Item> items;
+    for (int p = 0; p < n_plans; ++p) {
+        const TilePlanHost &P = *plans[p];
+        for (int64_t t = 0; t < P.n_tasks; ++t)
+            items.push_back({p == 0 ? (int32_t)t : ~(int32_t)t, P.task_work[(size_t)t],
+                             ((int64_t)p << 40) | (int64_t)P.task_w0[(size_t)t]});
+    }
+    const size_t n = items.size();
+    order.assign(n, 0);
+    if (n == 0) return;
+    n_xcd = std::max(1, n_xcd);
+    bundle = std::max(1, bundle);
+    // tasks of one range together, longest first
+    std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) {
+        return x.key != y.key ? x.key < y.key : x.work > y.work;
+    });
+    struct Bundle { size_t first, count; int64_t longest, total; };
+    std::vector<Bundle> bundles;
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        int64_t total = 0;
+        while (j < n && items[j].key == items[i].key && j - i < (size_t)bundle) total += items[j++].work;
+        bundles.push_back({i, j - i, items[i].work, total});
+        i = j;
+    }
+    std::stable_sort(bundles.begin(), bundles.end(), [](const Bundle &x, const Bundle &y) { return x.longest > y.longest; });
+    std::vector<std::vector<int32_t>> queue((size_t)n_xcd);
+    std::vector<int64_t> load((size_t)n_xcd, 0);
+    for (const Bundle &b : bundles) {
+        int x = 0;
+        for (int c = 1; c < n_xcd; ++c)
+            if (load[(size_t)c] < load[(size_t)x]) x = c;
+        for (size_t i = b.first; i < b.first + b.count; ++i) queue[(size_t)x].push_back(items[i].code);
+        load[(size_t)x] += b.total;
+    }
+    // XCD x owns the slots x, x + n_xcd, ...: move the (short) tail tasks of over-full queues
+    auto slots_of = [&](int x) { return (n - (size_t)x + (size_t)n_xcd - 1) / (size_t)n_xcd; };
+    for (int x = 0; x < n_xcd; ++x)
+        while (queue[(size_t)x].size() > slots_of(x)) {
+            int y = 0;
+            while (queue[(size_t)y].size() >= slots_of(y)) ++y;     // exists: the sizes add up to n
+            queue[(size_t)y].push_back(queue[(size_t)x].back());
+            queue[(size_t)x].pop_back();
+        }
+    for (int x = 0; x < n_xcd; ++x)
+        for (size_t q = 0; q < queue[(size_t)x].size(); ++q) order[q * (size_t)n_xcd + (size_t)x] = queue[(size_t)x][q];
 }
 
 // with P.steps known: task work / merged-launch order, where every (block, wave)'s entries start
@@ -528,23 +584,28 @@ void tile_plan_report(const TilePlanHost &P)
 template <typename CntBelow>
 static void ring_schedule_block(const TilePlanHost &P, int64_t b, CntBelow cnt_below, int32_t *start, uint32_t *T)
 {
-    const int W = P.n_windows, gpb = P.gpb, L = P.ring;
+    const int W = P.n_windows, gpb = P.gpb;
     const int64_t wpt = P.windows_per_task;
     std::vector<int32_t> done((size_t)gpb, 0);
     for (int e = 0; e < W; ++e) {
         const int w1 = (int)std::min<int64_t>((e / wpt + 1) * wpt, W);   // end of the task e belongs to
-        const int hor = std::min(e + L - 1, w1);
-        int32_t need = 0;
-        for (int g = 0; g < gpb; ++g) need = std::max(need, cnt_below(b, g, e + 1) - done[(size_t)g]);
+        const int hor = std::min(e + P.look + 1, w1);
+        // asynchronous ring: one T_e for the workgroup (its waves meet only through the slot counters),
         // rounded up to the depth of the kernel's entry prefetch ring (4): an epoch then starts with
         // its first entries in ring slots 0..3 and the prefetch distance survives the boundary.  The
         // extra steps are not lost: rows with nonzeros inside the horizon work ahead in them.
-        const uint32_t Te = (uint32_t)(((need + 1) / 2 + 3) / 4 * 4);
-        T[e] = Te;
-        for (int g = 0; g < gpb; ++g) {
-            start[(size_t)g * (W + 1) + e] = done[(size_t)g];
-            const int32_t avail = cnt_below(b, g, hor) - done[(size_t)g];
-            done[(size_t)g] += std::min<int32_t>((int32_t)(2 * Te), avail);
+        // Half-window schedule: the waves meet at the barrier anyway, every wave has its own T_e.
+        const int span = P.sync_stage ? P.gpw : gpb;
+        for (int g0 = 0; g0 < gpb; g0 += span) {
+            int32_t need = 0;
+            for (int g = g0; g < g0 + span; ++g) need = std::max(need, cnt_below(b, g, e + 1) - done[(size_t)g]);
+            const uint32_t Te = P.sync_stage ? (uint32_t)((need + 1) / 2) : (uint32_t)(((need + 1) / 2 + 3) / 4 * 4);
+            for (int v = g0 / P.gpw; v < (g0 + span) / P.gpw; ++v) T[(size_t)v * W + e] = Te;
+            for (int g = g0; g < g0 + span; ++g) {
+                start[(size_t)g * (W + 1) + e] = done[(size_t)g];
+                const int32_t avail = cnt_below(b, g, hor) - done[(size_t)g];
+                done[(size_t)g] += std::min<int32_t>((int32_t)(2 * Te), avail);
+            }
         }
     }
     for (int g = 0; g < gpb; ++g) start[(size_t)g * (W + 1) + W] = done[(size_t)g];
@@ -605,7 +666,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     } else {
         parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int t) {
             std::vector<int32_t> below((size_t)gpb * ((size_t)W + 1));   // nonzeros of lane g with window < w
-            std::vector<uint32_t> T((size_t)W);
+            std::vector<uint32_t> T((size_t)wpb * W);
             for (int64_t b = b0; b < b1; ++b) {
                 for (int g = 0; g < gpb; ++g) {
                     int32_t *bl = below.data() + (size_t)g * (W + 1);
@@ -622,9 +683,9 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                 }
                 ring_schedule_block(P, b, [&](int64_t, int g, int w) { return below[(size_t)g * (W + 1) + w]; },
                                     starts.data() + (size_t)b * gpb * ((size_t)W + 1), T.data());
-                for (int e = 0; e < W; ++e) {
-                    if (T[(size_t)e] > 65535u) { err[(size_t)t] = 1; continue; }
-                    for (int v = 0; v < wpb; ++v) P.steps[((size_t)b * wpb + v) * W + e] = (uint16_t)T[(size_t)e];
+                for (size_t i = 0; i < (size_t)wpb * W; ++i) {   // T[wave][epoch]
+                    if (T[i] > 65535u) { err[(size_t)t] = 1; continue; }
+                    P.steps[(size_t)b * wpb * W + i] = (uint16_t)T[i];
                 }
             }
         });

@@ -137,11 +137,21 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 //    to e+ring-2, never beyond its task).  Rows that fall behind in one
 //    sub-window have usually worked ahead before: at C3 0.88-0.91 of the slots carry nonzeros,
 //    and the staging copy never stalls the compute.  steps[] then holds T_e for every wave.
+//
+//  * HALF-WINDOW schedule (ring >= 2, sync_stage): the ring schedule with few, large slots that
+//    are refilled AT the epoch boundary by the window schedule's own exposed copy (every slot is
+//    readable during an epoch, a row works ahead in up to ring - 1 slots).  With two slots of half
+//    a window the workgroup still stages exactly the bytes of the window schedule, meets at twice as
+//    many barriers, and the kernel is the window kernel with a different staging range; the
+//    schedule evens out half of the lock-step loss (simulated fill 0.80-0.83 against 0.68).
 struct TilePlanHost {
     int n_major = 0, n_minor = 0;
     int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
     int win_rows = 0, n_windows = 0, windows_per_task = 0;
     int ring = 1, slot16 = 0;             // ring mode: slots in the LDS ring, 16-byte units per slot
+    int look = 0;                         // ring mode: sub-windows beyond the epoch's own a row may work ahead in
+    int sync_stage = 0;                   // ring mode: 0 = asynchronous ring; 1 = slots refilled AT the epoch boundary (all
+                                          // slots readable, look = ring - 1, every wave its own step counts)
     int row_slots = 0;                    // 16-byte units per table row (KP * sizeof(T) / 16)
     int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
     bool packed = false;                  // 8-byte entries {idx0|idx1<<16, cnt0|cnt1<<16} instead of 16-byte
@@ -164,9 +174,22 @@ struct TilePlanHost {
 struct TileShape {
     int lpc = 1, waves_per_block = 16, win_rows = 1, target_tasks = 0, row_slots = 1;
     int ring = 1, slot_bytes = 0;
+    int sync_stage = 0;        // ring mode: 1 = the HALF-WINDOW schedule above (ring >= 2 then)
     int slots = 0;          // workgroups of this orientation the GPU runs at once (0: unknown); see tile_plan_begin
     bool bank_order = true, allow_packed = true;
 };
+// Launch order (slot -> task) of the tile sweep over one or two plans' tasks that keeps the tasks
+// reading the SAME window range of the minor table on ONE XCD at the same time: an XCD's 32 compute
+// units then stage the same table rows within a short time of each other and all but the first copy
+// of a window hit the XCD's own 4 MiB L2 (the tables do not fit it: C5 share 11-56 MB; measured there
+// 48 % L2 hits with the longest-first order).  Workgroup s is observed to run on XCD s % n_xcd
+// (MI355X_MICROARCH.md, dispatch): tasks of one (plan, range) are cut into bundles of `bundle` (the
+// workgroups an XCD holds at a time), bundles go longest first to the XCD with the least work so far
+// and XCD x's queue fills the slots x, x + n_xcd, ...  A wrong placement guess is slower, never wrong.
+// order[slot] = task of plans[0], or ~task of plans[1].
+void xcd_launch_order(const TilePlanHost *const *plans, int n_plans, int n_xcd, int bundle,
+                      std::vector<int32_t> &order);
+
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                      int n_major, int n_minor, const TileShape &shape, bool keep_order, TilePlanHost &out);
 
@@ -175,7 +198,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
 // boundaries with every step in its slot (the padding steps are loaded, never executed).
 inline int64_t tile_stored_steps(const TilePlanHost &P, int steps)
 {
-    return P.ring > 1 ? (int64_t)((steps + 3) / 4 * 4) : (int64_t)steps;
+    return P.ring > 1 && !P.sync_stage ? (int64_t)((steps + 3) / 4 * 4) : (int64_t)steps;
 }
 
 // LDS position (16-byte units) of minor row m: shared by both builders and the test hook

@@ -70,7 +70,7 @@ __global__ void fill_i64_kernel(int64_t n, int64_t v, int64_t *__restrict__ out)
 
 struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
-    int ring, slot16, wpt;
+    int ring, slot16, wpt, look, sync_stage;
 };
 
 // LDS position of minor row m in 16-byte units (plan.h tile_off16)
@@ -149,21 +149,29 @@ __global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const i
     };
     for (int e = 0; e < g.W; ++e) {
         const int w1 = min((e / g.wpt + 1) * g.wpt, g.W);
-        const int hor = min(e + g.ring - 1, w1);
+        const int hor = min(e + g.look + 1, w1);
         c_need = advance(c_need, ((int64_t)e + 1) * g.win_rows);
         if (c_hor < c_need) c_hor = c_need;
         c_hor = advance(c_hor, (int64_t)hor * g.win_rows);
         int need = (int)(c_need - r0) - done;
-        // block maximum
-        for (int m = 32; m >= 1; m >>= 1) need = max(need, __shfl_xor(need, m, 64));
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = need;
-        __syncthreads();
-        need = 0;
-        for (int v = 0; v < (int)(blockDim.x >> 6); ++v) need = max(need, red[v]);
-        __syncthreads();
-        const unsigned Te = (unsigned)(((need + 1) / 2 + 3) / 4 * 4);   // plan.cpp::ring_schedule_block
+        // maximum over the sweep kernel's wave (gpw lane groups, a power of two <= 64) ...
+        for (int m = g.gpw >> 1; m >= 1; m >>= 1) need = max(need, __shfl_xor(need, m, 64));
+        if (!g.sync_stage) {   // ... asynchronous ring: over the block
+            for (int m = 32; m >= g.gpw; m >>= 1) need = max(need, __shfl_xor(need, m, 64));
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = need;
+            __syncthreads();
+            need = 0;
+            for (int v = 0; v < (int)(blockDim.x >> 6); ++v) need = max(need, red[v]);
+            __syncthreads();
+        }
+        const unsigned Te = g.sync_stage ? (unsigned)((need + 1) / 2)
+                                         : (unsigned)(((need + 1) / 2 + 3) / 4 * 4);   // plan.cpp::ring_schedule_block
         if (Te > 65535u) *err = 1;
-        if (gi < g.wpb) steps32[((size_t)b * g.wpb + gi) * g.W + e] = Te;
+        if (g.sync_stage) {
+            if (owner && gi % g.gpw == 0) steps32[((size_t)b * g.wpb + gi / g.gpw) * g.W + e] = Te;
+        } else if (gi < g.wpb) {
+            steps32[((size_t)b * g.wpb + gi) * g.W + e] = Te;
+        }
         if (owner) st[e] = done;
         done += min((int32_t)(2 * Te), (int32_t)(c_hor - r0) - done);
     }
@@ -327,6 +335,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         g.n_classes = shape.bank_order ? std::max(1, 16 / std::max(1, lpc)) : 1;
         g.row_slots = P.row_slots;
         g.ring = P.ring; g.slot16 = P.slot16; g.wpt = P.windows_per_task;
+        g.look = P.look; g.sync_stage = P.sync_stage;
         const bool ring = P.ring > 1;
         const int64_t n_slots = P.n_blocks * P.gpb;
         Tmp d_rows((size_t)n_slots * 4);

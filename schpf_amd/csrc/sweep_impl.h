@@ -576,23 +576,32 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
 
+    // asynchronous global -> LDS copy (global_load_lds_dwordx4): a wave instruction moves 1 KiB (LDS
+    // address = wave-uniform base + 16 * lane), no staging registers and every piece in flight at
+    // once; the __syncthreads that follows drains them (vmcnt(0)) first
+    auto stage = [&](int sw, int slot) {
+        const int r0 = sw * a.win_rows;
+        const int nr = min(a.win_rows, a.n_minor - r0);
+        const unsigned char *__restrict__ src = reinterpret_cast<const unsigned char *>(a.tab_minor + (size_t)r0 * KP);
+        unsigned char *dst = lds_raw + (size_t)slot * a.slot_bytes;
+        const int nbytes = nr * KP * (int)sizeof(T);                  // a multiple of 16
+        for (int off = wv * 1024; off < nbytes; off += a.wpb * 1024) {   // scalar loop
+            const int o = off + lane * 16;
+            if (o < nbytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                                 (__attribute__((address_space(3))) void *)(dst + off), 16, 0, 0);
+        }
+    };
+    // Window schedule: the whole LDS is window w, refilled between two barriers.  Half-window
+    // schedule (a.ring slots, plan.h): the first epoch fills every slot, a later one only the slot
+    // that the last epoch's own sub-window had.
+    const int L = a.ring > 1 ? a.ring : 1;
     for (int w = w0; w < w1; ++w) {
         if (MODE != MODE_RANDOM) {
             __syncthreads();                       // previous window fully consumed
-            const int r0 = w * a.win_rows;
-            const int nr = min(a.win_rows, a.n_minor - r0);
-            // asynchronous global -> LDS copy (global_load_lds_dwordx4): a wave instruction moves
-            // 1 KiB (LDS address = wave-uniform base + 16 * lane), no staging registers and every
-            // piece of the window in flight at once; __syncthreads drains them (vmcnt(0)) first
-            const unsigned char *__restrict__ src = reinterpret_cast<const unsigned char *>(a.tab_minor + (size_t)r0 * KP);
-            const int nbytes = nr * KP * (int)sizeof(T);                  // a multiple of 16
-            for (int off = wv * 1024; off < nbytes; off += a.wpb * 1024) {   // scalar loop
-                const int o = off + lane * 16;
-                if (o < nbytes)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(src + o),
-                        (__attribute__((address_space(3))) void *)(lds_raw + off), 16, 0, 0);
-            }
+            const int sw0 = (L == 1 || w == w0) ? w : w + L - 1;
+            const int sw1 = min(w + L, w1);
+            for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
         }
         if (PIPE) {
@@ -680,7 +689,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                         // t = 0 responsibilities (reference scHPF_.py:652-655), counter-based draws
 #pragma unroll 1
                         for (int u = 0; u < 2; ++u) {
-                            const unsigned minor = (unsigned)entry_minor(u ? i1 : i0, w, a.win_rows, KP * (int)sizeof(T) / 16, 1, 0);
+                            const unsigned minor = (unsigned)entry_minor(u ? i1 : i0, w, a.win_rows, KP * (int)sizeof(T) / 16, a.ring, a.slot_bytes / 16);
                             const double x = (double)(u ? xf1 : xf0);
                             if (!(x > 0.0)) continue;
                             const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
@@ -775,8 +784,8 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     }
     if (MODE == MODE_PHI && __builtin_expect(any_bad && live, 0)) {   // group-uniform; rare: see slow_nonzero
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
-                                        a.win_rows, 1, 0, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub, a.K,
-                                        out_row);
+                                        a.win_rows, a.ring, a.slot_bytes / 16, GPW, a.log_major + (size_t)major * KP,
+                                        a.log_minor, sub, a.K, out_row);
         return;
     }
     if (MODE == MODE_PHI) {
@@ -1143,7 +1152,7 @@ template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
 #ifdef SCHPF_WITH_RING
-    if (a.ring > 1) { tile_sweep_task_ring<T, NV, LPC, MODE, MAXT, PACK>(a, task); return; }
+    if (a.ring > 1 && !a.sync_stage) { tile_sweep_task_ring<T, NV, LPC, MODE, MAXT, PACK>(a, task); return; }
 #endif
     tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK>(a, task);
 }

@@ -15,13 +15,17 @@ from conftest import load_golden, golden_coo, synthetic_counts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["tile", "ring", "gather"])
+@pytest.fixture(autouse=True, params=["tile", "half", "ring", "gather"])
 def plan_kind(request, monkeypatch):
     """Every engine test runs on all sweep implementations: the LDS-staged tile plan with the window
-    schedule ("tile", what ships), with the experimental ring schedule when the library was built
+    schedule ("tile", what ships), with the half-window schedule ("half": SCHPF_HALF=2), with the
+    experimental ring schedule when the library was built
     with it ("ring": SCHPF_RING=4), and the L2-gather plan (selected by the library from
     SCHPF_PLAN at upload time)."""
-    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param == "ring" else request.param)
+    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param in ("ring", "half") else request.param)
+    monkeypatch.delenv("SCHPF_HALF", raising=False)
+    if request.param == "half":
+        monkeypatch.setenv("SCHPF_HALF", "2")
     if request.param == "ring":
         from schpf_amd import _lib
         if b"+ring" not in _lib.load().schpf_version():
@@ -302,6 +306,27 @@ def test_mass_conservation_at_headline_shape(amd, oracle, plan_kind):
     assert_allclose((ths - a).sum(0), (bes - c).sum(0), rtol=1e-10)
     want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, ths, thr, bes, ber, nthreads=8)
     assert_allclose(loss, want, rtol=1e-11)
+
+
+def test_xcd_launch_order_changes_nothing_but_the_order(amd, oracle, plan_kind, monkeypatch):
+    """SCHPF_XCD=8 (plan.h xcd_launch_order: same-range tasks share an XCD) permutes the launch slots of
+    the merged sweep; every task still runs exactly once, so the iteration is bitwise the same."""
+    if plan_kind not in ("tile", "half"):
+        pytest.skip("the merged launch order belongs to the tile plan")
+    X = synthetic_counts(3000, 2500, 0.05, seed=11)
+    K, a, c = 20, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=3)
+    got = []
+    for xcd in ("1", "8"):
+        monkeypatch.setenv("SCHPF_XCD", xcd)
+        monkeypatch.setenv("SCHPF_TASKS", "300")
+        with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+            for _ in range(2):
+                eng.step()
+            got.append((eng.get_gamma("theta"), eng.get_gamma("beta"), eng.plan_info()["n_chunks_cell"]))
+    assert got[0][2] > 8                                     # several tasks per XCD queue
+    for x, y in zip(got[0][:2], got[1][:2]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
 def test_engine_argument_errors(amd):
