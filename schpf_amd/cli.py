@@ -1,12 +1,12 @@
-"""`scHPF train | train-pool | score | project`: command-line entry points over the loaders,
-run_trials and the model methods -- argument plumbing only, no logic of its own.
+"""`scHPF prep | prep-like | train | train-pool | score | project`: command-line entry points over
+the loaders, run_trials and the model methods -- argument plumbing only, no logic of its own.
 
 Same sub-commands, options, defaults and output file names as the reference's script
-(/root/reference/bin/scHPF:134-292 options; :370-470 train, :485-534 score, :536-559 project),
+(/root/reference/bin/scHPF:40-292 options; :317-366 prep / prep-like, :370-470 train, :485-534 score,
+:536-559 project),
 so a pipeline that calls `scHPF train -i X.mtx -o out -k 7 -t 5` keeps working and finds
 `out/scHPF_K7_b0_5trials.joblib` (the reference appends `_b{batchsize}` whenever ncells > batchsize,
-hence also for batchsize 0).  `prep` / `prep-like` (gene filtering against annotation files)
-are outside the accelerated path and are not provided.
+hence also for batchsize 0).
 """
 import argparse
 import json
@@ -59,6 +59,44 @@ def _parser():
     parser = argparse.ArgumentParser(prog="scHPF", description="scHPF on MI355X")
     sub = parser.add_subparsers(dest="cmd")
 
+    text_or_loom = ("a whitespace-delimited genes x cells UMI count matrix with two leading columns of gene "
+                    "attributes (ENSEMBL id, gene name), or a loom file with the row attribute `Accession` or `Gene`")
+    prep = sub.add_parser("prep", help="Filter genes and write the training matrix.")
+    prep.add_argument("-i", "--input", required=True, help="Input data: " + text_or_loom + ".")
+    prep.add_argument("-o", "--outdir", help="Output directory (created if missing; default: the input's).")
+    prep.add_argument("-p", "--prefix", default="", help="Prefix for output files.")
+    prep.add_argument("-m", "--min-cells", type=float, default=0.01,
+                      help="Keep genes observed in at least this many cells; a value in (0, 1) is a proportion "
+                           "of the cells. [0.01]")
+    prep.add_argument("-w", "--whitelist", default="",
+                      help="Two-column file (ENSEMBL id, gene name): keep only these genes.")
+    prep.add_argument("-b", "--blacklist", default="",
+                      help="Two-column file (ENSEMBL id, gene name): drop these genes, also when whitelisted.")
+    prep.add_argument("-nvc", "--n-validation-cells", type=int, default=0,
+                      help="Hold out this many randomly selected cells for validation. [0]")
+    prep.add_argument("-vgid", "--validation-group-ids", default=None,
+                      help="Single-column file of cell group ids (np.loadtxt): validation cells are spread "
+                           "about evenly over the groups.")
+    prep.add_argument("--validation-max-group-frac", type=float, default=0.5,
+                      help="With -vgid: the largest share of a group that may be held out. [0.5]")
+    prep.add_argument("--filter-by-gene-name", default=False, action="store_true",
+                      help="Match the white/blacklist by gene name instead of ENSEMBL id.")
+    prep.add_argument("--no-split-on-dot", default=False, action="store_true",
+                      help="Accepted for compatibility: the reference ignores it for `prep` (identifiers are "
+                           "always compared without their '.version' suffix), and so does this command.")
+
+    like = sub.add_parser("prep-like", help="Write a data set with the genes of another, in the same order.")
+    like.add_argument("-i", "--input", required=True, help="Input data: " + text_or_loom + ".")
+    like.add_argument("-r", "--reference", required=True,
+                      help="Two-column file (ENSEMBL id, gene name), e.g. prep's genes.txt: the genes to select "
+                           "from the input, in this order; all must be present.")
+    like.add_argument("-o", "--outdir", required=True, help="Output directory (created if missing).")
+    like.add_argument("-p", "--prefix", default="", help="Prefix for output files.")
+    like.add_argument("--by-gene-name", default=False, action="store_true",
+                      help="Match against the reference by gene name instead of ENSEMBL id.")
+    like.add_argument("--no-split-on-dot", default=False, action="store_true",
+                      help="Compare identifiers with their '.version' suffix.")
+
     train = sub.add_parser("train", help="Train a model (restarts run one after the other on one GPU, or "
                                          "spread over --devices).")
     _add_train_options(train)
@@ -97,6 +135,47 @@ def _load_matrix(path):
 def _write_args(args, path):
     with open(path, "w") as fh:
         json.dump(args.__dict__, fh, indent=2)
+
+
+def _write_matrix(path, X):
+    from scipy.io import mmwrite
+    mmwrite(path, X, field="integer")
+
+
+def _prep(args, outprefix):
+    """bin/scHPF:317-349: filtered.mtx, genes.txt, optionally the train / validation split."""
+    from .preprocessing import load_and_filter, split_validation_cells
+    filtered, genes = load_and_filter(args.input, min_cells=args.min_cells, whitelist=args.whitelist,
+                                      blacklist=args.blacklist, filter_by_gene_name=args.filter_by_gene_name,
+                                      no_split_on_dot=args.no_split_on_dot)
+    print("Writing filtered data to file.....")
+    _write_matrix("{}filtered.mtx".format(outprefix), filtered)
+    genes.to_csv("{}genes.txt".format(outprefix), sep="\t", header=None, index=None)
+    if args.n_validation_cells > 0:
+        print("Selecting train/validation cells.....")
+        Xtrn, Xvld, vld_ix = split_validation_cells(filtered, args.n_validation_cells, args.validation_group_ids,
+                                                    max_group_frac=args.validation_max_group_frac)
+        trn_ix = np.setdiff1d(np.arange(filtered.shape[0]), vld_ix)
+        print("Writing train/validation splits.....")
+        _write_matrix("{}train_cells.mtx".format(outprefix), Xtrn)
+        np.savetxt("{}train_cell_ix.txt".format(outprefix), trn_ix, fmt="%d")
+        _write_matrix("{}validation_cells.mtx".format(outprefix), Xvld)
+        np.savetxt("{}validation_cell_ix.txt".format(outprefix), vld_ix, fmt="%d")
+    print("Writing commandline arguments to file.....")
+    _write_args(args, "{}prep_commandline_args.json".format(outprefix))
+
+
+def _prep_like(args, outprefix):
+    """bin/scHPF:353-366."""
+    from .preprocessing import load_like
+    print("Loading and reordering input like reference.... ")
+    filtered, genes = load_like(args.input, reference=args.reference, by_gene_name=args.by_gene_name,
+                                no_split_on_dot=args.no_split_on_dot)
+    print("Writing prepared data to file.....")
+    _write_matrix("{}filtered.mtx".format(outprefix), filtered)
+    genes.to_csv("{}genes.txt".format(outprefix), sep="\t", header=None, index=None)
+    print("Writing commandline arguments to file.....")
+    _write_args(args, "{}prep-like_commandline_args.json".format(outprefix))
 
 
 def _train(args, outprefix):
@@ -206,7 +285,7 @@ def main(argv=None):
         parser.print_help(sys.stderr)
         return 1
     if args.outdir is None:     # the reference's defaults (bin/scHPF:305-311)
-        if args.cmd in ("train", "train-pool"):
+        if args.cmd in ("prep", "prep-like", "train", "train-pool"):
             args.outdir = args.input.rsplit("/", 1)[0] if "/" in args.input else "."
         elif args.cmd == "project":
             args.outdir = args.model.rsplit("/", 1)[0] if "/" in args.model else "."
@@ -217,7 +296,8 @@ def main(argv=None):
         os.makedirs(args.outdir)
     prefix = args.prefix.rstrip(".") + "." if args.prefix else ""
     outprefix = args.outdir + "/" + prefix
-    {"train": _train, "train-pool": _train, "score": _score, "project": _project}[args.cmd](args, outprefix)
+    {"prep": _prep, "prep-like": _prep_like, "train": _train, "train-pool": _train, "score": _score,
+     "project": _project}[args.cmd](args, outprefix)
     return 0
 
 

@@ -1,8 +1,11 @@
-"""The one helper of the reference's schpf/util.py that the CAVI loop uses."""
+"""Host-side helpers of the reference's schpf/util.py: the minibatch index stream the CAVI loop
+uses, the factor-quality summaries `scHPF score` writes, and the COO row split / collapse / insert
+helpers around the validation-cell split (util.py:116-215)."""
 import numpy as np
+from scipy.sparse import coo_matrix
 
 __all__ = ["minibatch_ix_generator", "mean_cellscore_fraction", "mean_cellscore_fraction_list",
-           "max_pairwise", "max_pairwise_table"]
+           "max_pairwise", "max_pairwise_table", "split_coo_rows", "collapse_coo_rows", "insert_coo_rows"]
 
 
 def minibatch_ix_generator(ncells, batchsize):
@@ -70,3 +73,41 @@ def max_pairwise_table(gene_scores, ntop_list=(50, 100, 150, 200, 250, 300)):
     return pd.DataFrame({"ntop": list(ntop_list), "max_overlap": [o.overlap for o in first],
                          "p_max": [o.p for o in first], "max2_overlap": [o.overlap for o in second],
                          "p_max2": [o.p for o in second]})
+
+
+def split_coo_rows(X, split_indices):
+    """(a, b): the rows of X listed in `split_indices` (in that order), and the others in their
+    original order, both as COO (reference util.py:116-140)."""
+    rest = np.setdiff1d(np.arange(X.shape[0]), split_indices)
+    csr = X.tocsr()
+    return csr[split_indices, :].tocoo(), csr[rest, :].tocoo()
+
+
+def collapse_coo_rows(coo):
+    """X without its empty rows, and the original indices of the rows kept (reference
+    util.py:143-160)."""
+    kept = np.flatnonzero(coo.getnnz(1) > 0)
+    return coo.tocsr()[kept].tocoo(), kept
+
+
+def insert_coo_rows(a, b, b_indices):
+    """The (a.rows + b.rows) x cols COO matrix whose rows `b_indices` (ascending, unique) are b's
+    rows and whose other rows are a's, each set in its own order -- the inverse of split_coo_rows
+    (reference util.py:163-215; same errors).  Built from the two index maps instead of a Python
+    loop over rows."""
+    if a.shape[1] != b.shape[1]:
+        raise ValueError("a.shape[1] must equal b.shape[1], received a with shape {} and b with shape {}".format(
+            a.shape, b.shape))
+    n_out = a.shape[0] + b.shape[0]
+    b_indices = np.asarray(b_indices)
+    if np.max(b_indices) >= n_out:
+        raise ValueError("Invalid row indices {} for array with a.shape[0] + b.shape[0] = {} + {} = {}".format(
+            b_indices, a.shape[0], b.shape[0], n_out))
+    if not np.all(np.diff(b_indices) > 0):
+        raise ValueError("`b_indices` must be ordered without repeats. Received {}".format(b_indices))
+    a, b = a.tocsr().tocoo(), b.tocsr().tocoo()                 # duplicates summed, row-major
+    a_rows = np.setdiff1d(np.arange(n_out), b_indices)          # where a's rows land
+    row = np.concatenate([a_rows[a.row], b_indices[b.row]])
+    order = np.argsort(row, kind="stable")
+    return coo_matrix((np.concatenate([a.data, b.data])[order], (row[order], np.concatenate([a.col, b.col])[order])),
+                      shape=(n_out, a.shape[1]))

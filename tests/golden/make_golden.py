@@ -29,6 +29,12 @@ What each file pins (reference file:line):
   pbmc_like_data.npz   the COO the reference's loader makes of its own test data
                        file tests/_data/PJ030merge...matrix.txt (data only)
   ref_model_f64.joblib a model file written by the reference's save_model
+  prep_data.npz        the `prep` / `prep-like` pipeline (preprocessing.py:138-495, util.py:116-215)
+                       on the reference's test matrix: load_and_filter with the list files
+                       prep_whitelist.txt (made here from the matrix's own gene table) and
+                       sample_blacklist.txt (the reference's tests/_data file, data only),
+                       load_like on a shuffled subset, seeded subsample_cell_ixs /
+                       split_validation_cells draws, insert_coo_rows
 """
 import os
 import sys
@@ -180,7 +186,76 @@ def make_validation(X, fname):
     np.savez_compressed(os.path.join(HERE, fname), **d)
 
 
+def make_prep(txt, fname):
+    """Outputs of the reference's prep pipeline on its own test matrix."""
+    import shutil
+    import pandas as pd
+    from schpf import util as ref_util
+    umis, genes = prep.load_txt(txt, verbose=False)
+    d = {}
+    # list files: a whitelist of ~80 % of the matrix's genes (version suffixes altered for some,
+    # so that the split-on-dot matters) plus strangers; the reference's own sample blacklist
+    rng = np.random.RandomState(5)
+    on = rng.rand(len(genes)) < 0.8
+    wl = genes.loc[on].copy()
+    bump = rng.rand(len(wl)) < 0.3
+    wl.loc[bump, 0] = wl.loc[bump, 0].str.split(".").str[0] + ".99"
+    wl = pd.concat([wl, pd.DataFrame({0: ["ENSG99999999999.1", "ENSG88888888888.2"], 1: ["NOPE1", "NOPE2"]})])
+    wl_file = os.path.join(HERE, "prep_whitelist.txt")
+    wl.to_csv(wl_file, sep="\t", header=None, index=None)
+    bl_file = os.path.join(HERE, "sample_blacklist.txt")
+    shutil.copyfile("/root/reference/tests/_data/sample_blacklist.txt", bl_file)
+    os.chmod(bl_file, 0o644)
+    for tag, kw in (("m2", dict(min_cells=2, whitelist=wl_file, blacklist=bl_file)),
+                    ("m5name", dict(min_cells=5, whitelist=wl_file, blacklist=bl_file, filter_by_gene_name=True)),
+                    ("frac_nosplit", dict(min_cells=0.05, whitelist=wl_file, no_split_on_dot=True)),
+                    ("m0", dict(min_cells=0))):
+        f, g = prep.load_and_filter(txt, verbose=False, **kw)
+        d["laf_%s_row" % tag], d["laf_%s_col" % tag], d["laf_%s_data" % tag] = f.row, f.col, f.data
+        d["laf_%s_shape" % tag] = np.array(f.shape)
+        d["laf_%s_genes" % tag] = g.values.astype(str)
+        d["laf_%s_index" % tag] = g.index.values
+    # load_like on a shuffled subset of the genes
+    perm = np.random.RandomState(9).choice(len(genes), len(genes) - 10, replace=False)
+    like_file = os.path.join(HERE, "prep_like_reference.txt")
+    genes.loc[perm].to_csv(like_file, sep="\t", header=None, index=None)
+    for tag, kw in (("id", {}), ("name", dict(by_gene_name=True)), ("nosplit", dict(no_split_on_dot=True))):
+        f, g = prep.load_like(txt, reference=like_file, **kw)
+        d["like_%s_row" % tag], d["like_%s_col" % tag], d["like_%s_data" % tag] = f.row, f.col, f.data
+        d["like_%s_index" % tag] = g.index.values
+    d["like_perm"] = perm
+    # masks
+    d["mask_min3"] = prep.min_cells_expressing_mask(umis, 3)
+    d["mask_frac"] = prep.min_cells_expressing_mask(umis, 0.1)
+    # seeded draws
+    np.random.seed(11)
+    d["sub_plain"] = prep.subsample_cell_ixs(100, 17)
+    groups = np.random.RandomState(2).randint(0, 4, 100)
+    groups[:3] = 7                                           # a tiny group
+    np.random.seed(12)
+    d["sub_groups"] = prep.subsample_cell_ixs(100, 30, group_ids=groups, max_group_frac=0.4)
+    np.random.seed(13)
+    d["sub_choices"] = prep.subsample_cell_ixs(np.arange(50, 150), 20, group_ids=groups, max_group_frac=0.5)
+    d["groups"] = groups
+    gid_file = os.path.join(HERE, "prep_group_ids.txt")
+    np.savetxt(gid_file, groups, fmt="%d")
+    np.random.seed(14)
+    Xt, Xv, vix = prep.split_validation_cells(umis, 20, gid_file, max_group_frac=0.5, verbose=False)
+    d["split_vix"] = vix
+    for nm, m in (("split_train", Xt), ("split_valid", Xv)):
+        d[nm + "_row"], d[nm + "_col"], d[nm + "_data"], d[nm + "_shape"] = m.row, m.col, m.data, np.array(m.shape)
+    back = ref_util.insert_coo_rows(Xt, Xv, vix)
+    d["insert_row"], d["insert_col"], d["insert_data"] = back.row, back.col, back.data
+    col, nz = ref_util.collapse_coo_rows(umis.T.tocoo())      # genes x cells: 77 empty gene rows
+    d["collapse_nz"] = nz
+    d["collapse_row"], d["collapse_col"], d["collapse_data"] = col.row, col.col, col.data
+    np.savez_compressed(os.path.join(HERE, fname), **d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "prep":
+        make_prep("/root/reference/tests/_data/PJ030merge.c300t400_g0t500.matrix.txt", "prep_data.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "validation":
         txt = "/root/reference/tests/_data/PJ030merge.c300t400_g0t500.matrix.txt"
         Xd, _genes = prep.load_txt(txt, verbose=False)
@@ -215,6 +290,7 @@ def main():
     make_project(m64, Xd, "project_data_k5_f64.npz")
     make_trials(Xd, "trials_data_k5_f64.npz")
     make_validation(Xd, "trials_validation_k5_f64.npz")
+    make_prep(txt, "prep_data.npz")
     schpf.save_model(m64, os.path.join(HERE, "ref_model_f64.joblib"))
     print("golden vectors written to", HERE)
 

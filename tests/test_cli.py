@@ -88,3 +88,46 @@ def test_train_then_project_from_the_shell(tmp_path):
     model, projected = joblib.load(model_file), joblib.load(proj)
     assert projected.beta == model.beta and projected.theta.dims == model.theta.dims
     assert len(model.loss) >= 2 and model.loss[-1] < model.loss[0]
+
+
+def test_prep_and_prep_like_write_the_reference_files(tmp_path):
+    """`scHPF prep` / `prep-like` (bin/scHPF:317-366): the files the reference writes, holding what the
+    reference's load_and_filter / split_validation_cells / load_like return (tests/golden/prep_data.npz)."""
+    from scipy.io import mmread
+    gold = np.load(os.path.join(GOLDEN, "prep_data.npz"))
+    txt = os.path.join(GOLDEN, "PJ030merge.c300t400_g0t500.matrix.txt")
+    out = tmp_path / "prepped"
+    p = __import__("schpf_amd.cli", fromlist=["_parser"])._parser()
+    a = p.parse_args(["prep", "-i", txt])
+    assert (a.min_cells, a.whitelist, a.blacklist, a.n_validation_cells, a.validation_max_group_frac) == \
+        (0.01, "", "", 0, 0.5)                                                             # bin/scHPF:58-88
+    np.random.seed(14)
+    assert run_cli("prep", "-i", txt, "-o", str(out), "-p", "pj", "-m", "0", "-nvc", "20", "-vgid",
+                   os.path.join(GOLDEN, "prep_group_ids.txt")) == 0
+    names = sorted(os.listdir(out))
+    assert names == ["pj.filtered.mtx", "pj.genes.txt", "pj.prep_commandline_args.json", "pj.train_cell_ix.txt",
+                     "pj.train_cells.mtx", "pj.validation_cell_ix.txt", "pj.validation_cells.mtx"]
+    f = mmread(str(out / "pj.filtered.mtx"))
+    assert np.array_equal(f.row, gold["laf_m0_row"]) and np.array_equal(f.col, gold["laf_m0_col"])
+    assert np.array_equal(f.data, gold["laf_m0_data"]) and f.data.dtype.kind == "i"
+    assert open(out / "pj.filtered.mtx").readline().split()[3] == "integer"
+    vix = np.loadtxt(out / "pj.validation_cell_ix.txt", dtype=int)
+    assert np.array_equal(vix, gold["split_vix"])
+    assert np.array_equal(np.loadtxt(out / "pj.train_cell_ix.txt", dtype=int), np.setdiff1d(np.arange(100), vix))
+    v = mmread(str(out / "pj.validation_cells.mtx"))
+    assert np.array_equal(v.row, gold["split_valid_row"]) and np.array_equal(v.data, gold["split_valid_data"])
+    t = mmread(str(out / "pj.train_cells.mtx"))
+    assert np.array_equal(t.col, gold["split_train_col"]) and t.shape == tuple(gold["split_train_shape"])
+    genes = np.loadtxt(out / "pj.genes.txt", dtype=str, delimiter="\t")
+    assert np.array_equal(genes, gold["laf_m0_genes"])
+
+    # filtered with lists; then a second data set prepared like the first
+    assert run_cli("prep", "-i", txt, "-o", str(out), "-p", "m2", "-m", "2", "-w", os.path.join(GOLDEN, "prep_whitelist.txt"),
+                   "-b", os.path.join(GOLDEN, "sample_blacklist.txt")) == 0
+    f = mmread(str(out / "m2.filtered.mtx"))
+    assert np.array_equal(f.col, gold["laf_m2_col"]) and f.shape == tuple(gold["laf_m2_shape"])
+    assert run_cli("prep-like", "-i", txt, "-r", str(out / "m2.genes.txt"), "-o", str(tmp_path / "like")) == 0
+    g = mmread(str(tmp_path / "like" / "filtered.mtx"))
+    assert np.array_equal(g.toarray(), f.toarray())
+    assert (tmp_path / "like" / "genes.txt").read_text() == (out / "m2.genes.txt").read_text()
+    assert (tmp_path / "like" / "prep-like_commandline_args.json").exists()
