@@ -24,20 +24,38 @@ __global__ __launch_bounds__(1024) void stage_kernel(const unsigned char *__rest
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off + lane * 16),
                                                  (__attribute__((address_space(3))) void *)(lds + off), 16, 0, 0);
         } else {
-            // registers: up to 10 x 16 B per lane in flight, then written
-            uint4 r[10];
-            int n = 0;
+            // registers: the wave's 1 KiB pieces as unconditional 16-byte loads (all in flight), then
+            // ds_write_b128; the pieces beyond the common count under a wave-uniform branch
+            const int n_piece = win_bytes / 1024;                 // 152
+            const int common = n_piece / wpb;                     // 9 for 16 waves
+            if (MODE == 1) {
+                uint4 r[9];
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int off = (wv + i * wpb) * 1024;
-                if (off < win_bytes) r[i] = *reinterpret_cast<const uint4 *>(src + off + lane * 16);
-            }
+                for (int i = 0; i < 9; ++i)
+                    if (i < common) r[i] = *reinterpret_cast<const uint4 *>(src + (size_t)(wv + i * wpb) * 1024 + lane * 16);
+                uint4 extra = make_uint4(0, 0, 0, 0);
+                const bool has_extra = wv + common * wpb < n_piece;
+                if (has_extra) extra = *reinterpret_cast<const uint4 *>(src + (size_t)(wv + common * wpb) * 1024 + lane * 16);
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int off = (wv + i * wpb) * 1024;
-                if (off < win_bytes) *reinterpret_cast<uint4 *>(lds + off + lane * 16) = r[i];
+                for (int i = 0; i < 9; ++i)
+                    if (i < common) *reinterpret_cast<uint4 *>(lds + (wv + i * wpb) * 1024 + lane * 16) = r[i];
+                if (has_extra) *reinterpret_cast<uint4 *>(lds + (wv + common * wpb) * 1024 + lane * 16) = extra;
+            } else {
+                // two batches of 5 (fewer registers)
+                for (int b = 0; b < 2; ++b) {
+                    uint4 r[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const int piece = wv + (b * 5 + i) * wpb;
+                        r[i] = piece < n_piece ? *reinterpret_cast<const uint4 *>(src + (size_t)piece * 1024 + lane * 16) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const int piece = wv + (b * 5 + i) * wpb;
+                        if (piece < n_piece) *reinterpret_cast<uint4 *>(lds + piece * 1024 + lane * 16) = r[i];
+                    }
+                }
             }
-            (void)n;
         }
         __syncthreads();
         acc += *reinterpret_cast<const float *>(lds + ((threadIdx.x * 16 + w * 4) % win_bytes));
@@ -54,13 +72,15 @@ int main()
     CK(hipMemset(tab, 1, tab_bytes));
     CK(hipFuncSetAttribute((const void *)stage_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void *)stage_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)stage_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int stride : {0, 1, 7}) for (int mode = 0; mode < 2; ++mode) for (int blocks : {256, 1024}) {
+    for (int stride : {0, 1, 7}) for (int mode = 0; mode < 3; ++mode) for (int blocks : {1024}) {
         const int n_win = 64;
         float best = 1e9f;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(stage_kernel<0>, dim3(blocks), dim3(1024), win_bytes, 0, tab, tab_bytes, win_bytes, n_win, stride, out);
+            else if (mode == 2) hipLaunchKernelGGL(stage_kernel<2>, dim3(blocks), dim3(1024), win_bytes, 0, tab, tab_bytes, win_bytes, n_win, stride, out);
             else hipLaunchKernelGGL(stage_kernel<1>, dim3(blocks), dim3(1024), win_bytes, 0, tab, tab_bytes, win_bytes, n_win, stride, out);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -69,7 +89,7 @@ int main()
         const double bytes = (double)blocks * n_win * win_bytes;
         const double per_win_us = best * 1e3 / (n_win * (blocks / 256.0));
         printf("stride %d mode %s blocks %4d: %.3f ms  %.2f TB/s  %.2f us per window per CU  %.1f B/clk/CU (2.4 GHz)\n", stride,
-               mode ? "regs" : "dma ", blocks, best, bytes / best / 1e9, per_win_us, win_bytes / (per_win_us * 2400.0));
+               mode == 0 ? "dma  " : mode == 1 ? "regs9" : "regs5", blocks, best, bytes / best / 1e9, per_win_us, win_bytes / (per_win_us * 2400.0));
     }
     return 0;
 }
