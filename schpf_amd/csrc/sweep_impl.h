@@ -1279,6 +1279,8 @@ static hipError_t launch_random_t(const SweepArgs<T> &a, uint64_t seed, int majo
 #define SCHPF_DISPATCH(nv, lpc, CALLEXPR)                                     \
     if (nv == 5 && lpc == 1) { constexpr int NV = 5; constexpr int LPC = 1; return CALLEXPR; } \
     if (nv == 5 && lpc == 2) { constexpr int NV = 5; constexpr int LPC = 2; return CALLEXPR; } \
+    if (nv == 7 && lpc == 4) { constexpr int NV = 7; constexpr int LPC = 4; return CALLEXPR; } /* K = 50 */ \
+    if (nv == 7 && lpc == 2) { constexpr int NV = 7; constexpr int LPC = 2; return CALLEXPR; } \
     return hipErrorInvalidValue;
 #else
 #define SCHPF_DISPATCH(nv, lpc, CALLEXPR)                                     \

@@ -105,6 +105,56 @@ def test_iterations_match_oracle(amd, oracle, dtype, case, flags):
         assert_allclose(loss, want, rtol=1e-5 if f32 else 1e-11)
 
 
+def _fuzz_matrix(rng):
+    """A random small problem: shape, K, fill, row / column skew, value range, COO order."""
+    from scipy.sparse import coo_matrix
+    N = int(rng.choice([2, 3, 7, 63, 64, 65, 200, 513, 1200]))       # one row has no variance: bp would be inf
+    G = int(rng.choice([2, 3, 31, 128, 129, 400, 1031, 2500]))
+    K = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 20, 33, 50, 64, 100]))
+    want = max(1, int(N * G * rng.choice([0.005, 0.03, 0.1, 0.4])))
+    want = min(want, 60000)
+    # skewed marginals: a few heavy cells / genes (what makes rows of a wave uneven)
+    pr = rng.gamma(rng.choice([0.3, 1.0, 5.0]), 1.0, N) + 1e-9
+    pc = rng.gamma(rng.choice([0.3, 1.0, 5.0]), 1.0, G) + 1e-9
+    row = rng.choice(N, want, p=pr / pr.sum()).astype(np.int32)
+    col = rng.choice(G, want, p=pc / pc.sum()).astype(np.int32)
+    top = int(rng.choice([3, 60, 65535, 200000]))                    # beyond 65535: the unpacked entry format
+    val = np.minimum(rng.negative_binomial(1, 0.3, want) + 1, top).astype(np.int64)
+    if top > 65535:
+        val[rng.randint(0, want, 3)] = top
+    X = coo_matrix((val, (row, col)), shape=(N, G))
+    X.sum_duplicates()
+    while np.var(X.sum(1)) == 0 or np.var(X.sum(0)) == 0:            # the empirical hyperparameters need a spread
+        X = (X + coo_matrix(([1], ([0], [0])), shape=(N, G))).tocoo()
+    order = rng.permutation(X.nnz)                                   # COO order is not guaranteed sorted
+    return coo_matrix((X.data[order], (X.row[order], X.col[order])), shape=(N, G)), K
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_problems_match_oracle(amd, oracle, seed):
+    """Seeded fuzz over shapes (1 x 1 upwards, off-by-one around the 64-lane and window sizes), K from 1 to
+    100, fill 0.5-40 %, heavy-tailed rows and columns, counts beyond 16 bits, shuffled COO order, both
+    dtypes and every ordering flag (1 x n matrices are left out: the reference's bp = mean / var of the row sums
+    is infinite there): two iterations and the loss against the oracle."""
+    rng = np.random.RandomState(1000 + seed)
+    X, K = _fuzz_matrix(rng)
+    dtype = [np.float64, np.float32][seed % 2]
+    flags = [{}, {"simultaneous": True}, {"freeze_genes": True}, {}][(seed // 2) % 4]
+    a, c = float(rng.choice([0.3, 1.0])), float(rng.choice([0.3, 0.05]))
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=seed, a=a, c=c)
+    f32 = np.dtype(dtype) == np.float32
+    with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+        for it in range(2):
+            eng.step(**flags)
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp, **flags)
+            compare_state(eng, st, rtol=(3e-5 * (it + 1)) if f32 else 1e-11)
+        loss = eng.mean_negative_pois_llh()
+        st64 = st.cast(np.float64)
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st64.theta_shape, st64.theta_rate,
+                                             st64.beta_shape, st64.beta_rate)
+        assert_allclose(loss, want, rtol=2e-5 if f32 else 1e-11)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_random_phi_first_iteration_matches_oracle(amd, oracle, dtype):
     """t == 0: responsibilities drawn on the host (reference scHPF_.py:652-655)."""
