@@ -270,6 +270,7 @@ template <typename T> struct Engine final : schpf_ctx {
     PlanDev cell, gene;                             // gather plans: major = cell / major = gene
     TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
     DevBuf dual_order;                              // merged launch order of both plans' tasks (or empty)
+    DevBuf dual_queue;                              // persistent dual launch: {next slot, workgroups done}, self-zeroing
     int64_t dual_slots = 0;
     bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
@@ -302,8 +303,14 @@ template <typename T> struct Engine final : schpf_ctx {
         if (stream_ == SCHPF_STREAM_DEFAULT) stream = nullptr;
         else if (stream_) stream = (hipStream_t)stream_;
         else { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); own_stream = true; }
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+                cu_count = prop.multiProcessorCount;
+        }
         choose_config();
         const size_t s = sizeof(T);
+        dual_queue.alloc(2 * sizeof(int), true, stream);
         xi_s.alloc((size_t)N * s); xi_r.alloc((size_t)N * s);
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
@@ -599,13 +606,8 @@ template <typename T> struct Engine final : schpf_ctx {
     // two workgroups per CU) until there are.  Measured on a 1/8 shard of C3 and on C2
     // (SCHPF_MIN_PAIRS = 768 / 256 / 128 / 64): the large workgroup wins well below one task per
     // CU, because both orientations share a launch and small windows cost padding and partials.
-    int n_cu() const
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            return prop.multiProcessorCount;
-        return 256;
-    }
+    int cu_count = 256;
+    int n_cu() const { return cu_count; }
     schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false) const
     {
         int wpb = env_int("SCHPF_WPB", 0);
@@ -1099,9 +1101,19 @@ template <typename T> struct Engine final : schpf_ctx {
             auto ac = tile_args(tcell, th_exp, be_exp, th_log, be_log, G);
             auto ag = tile_args(tgene, be_exp, th_exp, be_log, th_log, N);
             ac.major_is_cell = 1; ag.major_is_cell = 0;
+            // persistent workgroups (SCHPF_PERSISTENT=0: one workgroup per slot): as many as the device holds at
+            // once draw the slots of the longest-first list from a counter -- no workgroup teardown / launch
+            // between the ~6 tasks of a compute unit and whoever is free takes the next task: C3 sweep
+            // -2 % f64, -5 % f32, nothing at C2 / the C5 share (profiles/r02/explore_persistent.log)
+            const size_t lds = std::max(tcell.lds_bytes, tgene.lds_bytes);
+            int *queue = nullptr;
+            int resident = 0;
+            if (env_int("SCHPF_PERSISTENT", 1)) {
+                queue = dual_queue.as<int>();
+                resident = n_cu() * (lds > 80 * 1024 ? 1 : 2);
+            }
             HIPCHK(schpf::launch_tile_sweep_dual<T>(ac, ag, dual_order.as<int>(), NV, LPC, tcell.packed ? 1 : 0,
-                                                    dual_slots, tcell.threads, std::max(tcell.lds_bytes, tgene.lds_bytes),
-                                                    stream));
+                                                    dual_slots, tcell.threads, lds, queue, resident, stream));
             tm.stop();
         } else if (pending_init == 0) {
             if (do_gene && !freeze) {

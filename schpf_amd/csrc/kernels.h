@@ -77,10 +77,12 @@ hipError_t launch_random_phi(const SweepArgs<T> &a, int nv, int lpc, uint64_t se
 template <typename T>
 hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, int packed, int64_t n_tasks,
                              int threads, size_t lds_bytes, hipStream_t st);
-// cell-side (a0) and gene-side (a1) MODE_PHI sweeps in one launch; order[slot] = task | ~task
+// cell-side (a0) and gene-side (a1) MODE_PHI sweeps in one launch; order[slot] = task | ~task.
+// queue != nullptr (two zeroed ints): `resident` persistent workgroups draw the slots from it
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
-                                  int packed, int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st);
+                                  int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
+                                  hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);

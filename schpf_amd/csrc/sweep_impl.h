@@ -1168,13 +1168,35 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 // partials): order[slot] = task of the cell-side plan, or ~task of the gene-side plan, merged
 // longest-first.  One launch has one tail instead of two and the two task pools fill each
 // other's idle compute units.
+//
+// queue == nullptr: one workgroup per slot.  Otherwise PERSISTENT workgroups (as many as the device
+// holds at once): a workgroup starts on slot blockIdx.x and, when its task is done, draws the next
+// slot from queue[0] -- no workgroup launch / teardown between the tasks of a compute unit, and the
+// longest-first list is balanced by who is free, not by the dispatcher's round-robin.  queue[1]
+// counts the workgroups that have found the list empty; the last one zeroes both words for the
+// next launch.
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
-                                                              const int *__restrict__ order)
+                                                              const int *__restrict__ order, int n_slots,
+                                                              int *__restrict__ queue)
 {
-    const int code = order[blockIdx.x];
-    if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a0, code);
-    else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a1, ~code);
+    __shared__ int next_slot;
+    int slot = blockIdx.x;
+    for (;;) {
+        const int code = order[slot];
+        if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a0, code);
+        else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a1, ~code);
+        if (!queue) return;
+        __syncthreads();                                   // the window and next_slot are free again
+        if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&queue[0], 1);
+        __syncthreads();
+        slot = next_slot;
+        if (slot >= n_slots) break;
+    }
+    if (threadIdx.x == 0 && atomicAdd(&queue[1], 1) == (int)gridDim.x - 1) {
+        queue[0] = 0;
+        queue[1] = 0;
+    }
 }
 
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
@@ -1217,31 +1239,35 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
 
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
-                                int threads, size_t lds_bytes, hipStream_t st)
+                                int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
 {
     if (lds_bytes > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
+            // not the full 160 KiB: the kernel has a static word of LDS of its own (next_slot)
             hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
-    hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>), dim3((unsigned)n_slots),
-                       dim3((unsigned)threads), lds_bytes, st, a0, a1, order);
+    if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
+    const unsigned grid = queue ? (unsigned)resident : (unsigned)n_slots;
+    hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>), dim3(grid), dim3((unsigned)threads), lds_bytes,
+                       st, a0, a1, order, (int)n_slots, queue);
     return hipGetLastError();
 }
 template <typename T, int NV, int LPC>
 static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int packed,
-                                int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st)
+                                int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
+                                hipStream_t st)
 {
     if (n_slots == 0) return hipSuccess;
     if (threads <= 512)
-        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, st)
-                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, st);
-    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, st)
-                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, st);
+        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
+    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
 }
 
 // ------------------------------------------------------------------------ launchers
@@ -1335,9 +1361,11 @@ hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, in
 
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
-                                  int packed, int64_t n_slots, int threads, size_t lds_bytes, hipStream_t st)
+                                  int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
+                                  hipStream_t st)
 {
-    SCHPF_DISPATCH_TILE(nv, lpc, (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, st)))
+    SCHPF_DISPATCH_TILE(nv, lpc,
+                        (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, queue, resident, st)))
 }
 
 }  // namespace schpf
