@@ -174,7 +174,8 @@ __device__ __forceinline__ T group_dot(const T (&x)[KL], const T (&y)[KL])
             a0 = __builtin_elementwise_fma(x0, y0, a0);
             a1 = __builtin_elementwise_fma(x1, y1, a1);
         }
-        t = (a0.x + a0.y) + (a1.x + a1.y);
+        const f32x2 h = a0 + a1;     // one v_pk_add_f32, then one add (pairwise sums first cost three moves more)
+        t = h.x + h.y;
     } else {
         T s0 = T(0), s1 = T(0);
 #pragma unroll
