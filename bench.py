@@ -420,7 +420,8 @@ def main():
     b_launch = b_iter / per_iter
     achieved = b_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     info = eng.plan_info()
-    traffic, traffic_src = static_traffic(args.config, args.dtype, info) if world == 1 else (None, None)
+    # the counters were collected on the one-launch (dual) iteration of a single GPU
+    traffic, traffic_src = static_traffic(args.config, args.dtype, info) if not sharded else (None, None)
 
     out = {
         "metric": "CAVI iterations/sec, 100kx20k K=20" if args.config == "c3"
