@@ -379,6 +379,31 @@ def test_xcd_launch_order_changes_nothing_but_the_order(amd, oracle, plan_kind, 
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
+def test_persistent_dual_launch_equals_one_workgroup_per_task_bitwise(amd, oracle, plan_kind, monkeypatch):
+    """The dual sweep launch as persistent workgroups that draw tasks from a device counter (default)
+    against one workgroup per task (SCHPF_PERSISTENT=0), with more tasks than the device holds at once so
+    that the counter is actually used, over several launches (the counter re-arms itself): bitwise equal."""
+    if plan_kind not in ("tile", "half"):
+        pytest.skip("the dual launch belongs to the tile plan")
+    X = synthetic_counts(20000, 8000, 0.015, seed=12)        # 40 blocks x 9 windows + 16 x 21: > 256 tasks
+    K, a, c = 20, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=4)
+    got = []
+    for persistent in ("1", "0"):
+        monkeypatch.setenv("SCHPF_PERSISTENT", persistent)
+        monkeypatch.setenv("SCHPF_TASKS", "2000")
+        monkeypatch.setenv("SCHPF_WPB", "16")
+        with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+            for _ in range(3):
+                eng.step()
+            eng.steps(4)                                     # and inside a captured graph
+            info = eng.plan_info()
+            got.append((eng.get_gamma("theta"), eng.get_gamma("beta"), info["n_waves_cell"] + info["n_waves_gene"]))
+    assert got[0][2] == got[1][2] and got[0][2] > 300        # tasks of both orientations
+    for x, y in zip(got[0][:2], got[1][:2]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+
+
 def test_engine_argument_errors(amd):
     X = synthetic_counts(50, 60, 0.1)
     with pytest.raises(ValueError):
