@@ -301,6 +301,9 @@ def main():
                     help="skip the wall-clock-to-convergence fits (second half of BASELINE.json's metric)")
     args = ap.parse_args()
 
+    # the host driver of these boxes only supports dmabuf IPC: without this RCCL fails at the first
+    # cross-process buffer exchange (hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
