@@ -290,10 +290,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded driver (process group, exchange all-reduce) even with one rank")
-    ap.add_argument("--graph", action="store_true",
-                    help="time the steps as ONE schpf_steps call (a hipGraph replay, what scHPF.fit issues "
-                         "between two loss checks); the kernel times for the roofline then come from a "
-                         "second, eager pass.  Default for the launch-bound config c2.")
+    ap.add_argument("--eager", action="store_true",
+                    help="single GPU: one library call (three launches) per timed iteration instead of ONE "
+                         "schpf_steps call for all of them.  The default is the schpf_steps call -- a hipGraph "
+                         "replay, what scHPF.fit issues between two loss checks; the kernel times for the "
+                         "roofline then come from a second, eager pass.")
     ap.add_argument("--comm", default="library", choices=["library", "torch"],
                     help="sharded runs: all-reduce issued by the library (RCCL bound at run time, one call per "
                          "stretch of iterations) or by torch.distributed from Python (ShardedCAVI)")
@@ -339,10 +340,11 @@ def main():
     init_engine(eng, X, K, dtype)
     upload_s = time.perf_counter() - t_up
     nnz_local = X.nnz
-    # one library call for all K timed iterations: a hipGraph replay on one GPU (launch-bound configs),
-    # and always for sharded runs with the library's collective (the launch queue stays full: -12 % per
-    # iteration against one call per iteration; SCHPF_GRAPH_SHARDED=1 also captures them in a graph)
-    use_graph = ((args.graph or args.config == "c2") and not sharded) or (sharded and args.comm == "library")
+    # one library call for all K timed iterations, as scHPF.fit issues them between two loss checks: a
+    # hipGraph replay on one GPU (an odd K: K - 1 iterations replayed + one eager), and for sharded runs
+    # with the library's collective one call that keeps the launch queue full (-12 % per iteration against
+    # one call per iteration; SCHPF_GRAPH_SHARDED=1 also captures those in a graph)
+    use_graph = (not args.eager and not sharded) or (sharded and args.comm == "library")
     if sharded and args.comm == "library":
         from schpf_amd.sharded import NativeShard
         # rank 0's communicator id reaches the other ranks through the process group that is there anyway
