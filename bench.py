@@ -458,6 +458,10 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_gb_per_launch": b_launch / 1e9, "sweep_launches_per_iteration": per_iter,
             "avg_launch_ms": sweep_ms, "launches": sweeps,
+            "timed_with": ("HIP events on the engine's stream around every launch, over a second pass of the same %d "
+                           "iterations issued eagerly right after the timed call (events cannot sit inside the "
+                           "replayed hipGraph)" % args.steps) if use_graph and not sharded
+                          else "HIP events on the engine's stream around every launch of the timed iterations",
             "cell_sweep_ms": prof["cell_sweep"]["ms"] / max(prof["cell_sweep"]["launches"], 1),
             "gene_sweep_ms": prof["gene_sweep"]["ms"] / max(prof["gene_sweep"]["launches"], 1),
             "gamma_updates_ms": prof["gamma_updates"]["ms"] / max(prof["gamma_updates"]["launches"], 1),
