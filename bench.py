@@ -460,7 +460,7 @@ def main():
             "avg_launch_ms": sweep_ms, "launches": sweeps,
             "timed_with": ("HIP events on the engine's stream around every launch, over a second pass of the same %d "
                            "iterations issued eagerly right after the timed call (events cannot sit inside the "
-                           "replayed hipGraph)" % args.steps) if use_graph and not sharded
+                           "replayed hipGraph / the single library call)" % args.steps) if use_graph
                           else "HIP events on the engine's stream around every launch of the timed iterations",
             "cell_sweep_ms": prof["cell_sweep"]["ms"] / max(prof["cell_sweep"]["launches"], 1),
             "gene_sweep_ms": prof["gene_sweep"]["ms"] / max(prof["gene_sweep"]["launches"], 1),
