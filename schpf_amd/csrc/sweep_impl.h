@@ -17,6 +17,7 @@
 // limiter of this gather, profiles/r01) charges for.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <type_traits>
 
@@ -1200,21 +1201,31 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, T
     }
 }
 
+// The opt-in to more than 64 KiB of dynamic LDS is a per-DEVICE property of a kernel: one bit per device
+// and instantiation (a process may drive several GPUs: scHPF.fit(devices=...), run_trials_pool).  Returns
+// whether the calling thread's current device still has to raise it, and marks it raised.
+static inline bool lds_opt_in_pending(std::atomic<uint64_t> &raised)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: raise every time
+    const uint64_t bit = (uint64_t)1 << dev;
+    return (raised.fetch_or(bit) & bit) == 0;
+}
+
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 static hipError_t launch_tile_b(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
 {
     dim3 grid((unsigned)n_tasks), block((unsigned)threads);
     if (lds_bytes > 64 * 1024) {   // opt in to the full 160 KiB of a CU, once per instantiation
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<uint64_t> raised{0};
+        if (lds_opt_in_pending(raised)) {
             hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
+            if (e != hipSuccess) { raised = 0; return e; }
         }
     }
     if (mode == MODE_PHI)
@@ -1243,13 +1254,12 @@ static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, co
                                 int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
 {
     if (lds_bytes > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
+        static std::atomic<uint64_t> raised{0};
+        if (lds_opt_in_pending(raised)) {
             // not the full 160 KiB: the kernel has a static word of LDS of its own (next_slot)
             hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
+            if (e != hipSuccess) { raised = 0; return e; }
         }
     }
     if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
