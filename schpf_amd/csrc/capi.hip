@@ -115,6 +115,7 @@ struct PlanDev {
 struct TileDev {
     schpf::TilePlanHost host;   // entries/steps cleared after upload; order/mptr kept
     DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, pfirst, pcount, partials;
+    DevBuf task_order;          // tasks by decreasing work: the slot list of a persistent single-side launch
     DevBuf order_dev;           // device-built plans: (major, minor)-sorted position -> caller's COO position
     bool order_identity = false; //                    ... or the input was already in that order
     int64_t n_tasks = 0, entry_slots = 0, n_wave_out = 0;
@@ -554,6 +555,7 @@ template <typename T> struct Engine final : schpf_ctx {
         upload(td.task_w0, h.task_w0, stream);
         upload(td.task_w1, h.task_w1, stream);
         upload(td.task_wave_off, h.task_wave_off, stream);
+        upload(td.task_order, h.task_order, stream);
         upload(td.pfirst, h.pfirst, stream);
         upload(td.pcount, h.pcount, stream);
         td.partials.alloc((size_t)std::max<int64_t>(h.n_partial_rows, 1) * KP * sizeof(T), true, stream);
@@ -1011,6 +1013,11 @@ template <typename T> struct Engine final : schpf_ctx {
             TileDev &td = cellside ? tcell : tgene;
             auto a = tile_args(td, tmaj, tmin, lmaj, lmin, cellside ? G : N);
             a.seed = seed; a.major_is_cell = cellside ? 1 : 0;
+            if (mode != schpf::MODE_RANDOM && env_int("SCHPF_PERSISTENT", 1)) {   // see step_local
+                a.queue = dual_queue.as<int>();
+                a.resident = n_cu() * (td.lds_bytes > 80 * 1024 ? 1 : 2);
+                a.task_order = td.task_order.as<int>();
+            }
             HIPCHK(schpf::launch_tile_sweep<T>(a, NV, LPC, mode, td.packed ? 1 : 0, td.n_tasks, td.threads, td.lds_bytes, stream));
         } else {
             PlanDev &pd = cellside ? cell : gene;

@@ -43,6 +43,10 @@ template <typename T> struct TileArgs {
     int sync_stage;                // ring mode: half-window schedule (slots refilled at the epoch boundary)
     uint64_t seed;                 // MODE_RANDOM
     int major_is_cell;
+    // persistent launch (sweep_impl.h tile_sweep_kernel): `resident` workgroups draw the n_tasks slots of
+    // task_order from queue[0]; queue == nullptr: one workgroup per task
+    int *queue;
+    int n_tasks, resident;
 };
 
 template <typename T> struct UpdateArgs {

@@ -1160,11 +1160,26 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
 }
 
 // launch slot -> task: longest tasks first (plan.h task_order), so the launch has a short tail
+// a.queue: persistent workgroups, as in tile_sweep_dual_kernel below
 template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
-    const int task = a.task_order ? a.task_order[blockIdx.x] : (int)blockIdx.x;
-    tile_sweep_task<T, NV, LPC, MODE, MAXT, PACK>(a, task);
+    __shared__ int next_slot;
+    int slot = blockIdx.x;
+    for (;;) {
+        const int task = a.task_order ? a.task_order[slot] : slot;
+        tile_sweep_task<T, NV, LPC, MODE, MAXT, PACK>(a, task);
+        if (MODE == MODE_RANDOM || !a.queue) return;
+        __syncthreads();
+        if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&a.queue[0], 1);
+        __syncthreads();
+        slot = next_slot;
+        if (slot >= a.n_tasks) break;
+    }
+    if (threadIdx.x == 0 && atomicAdd(&a.queue[1], 1) == (int)gridDim.x - 1) {
+        a.queue[0] = 0;
+        a.queue[1] = 0;
+    }
 }
 // Both sweeps of an iteration in ONE launch (they read the same old tables and write disjoint
 // partials): order[slot] = task of the cell-side plan, or ~task of the gene-side plan, merged
@@ -1213,18 +1228,22 @@ static inline bool lds_opt_in_pending(std::atomic<uint64_t> &raised)
 }
 
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
-static hipError_t launch_tile_b(const TileArgs<T> &a, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
+static hipError_t launch_tile_b(const TileArgs<T> &a_in, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
 {
-    dim3 grid((unsigned)n_tasks), block((unsigned)threads);
+    TileArgs<T> a = a_in;
+    if (mode == MODE_RANDOM || a.resident <= 0 || a.resident >= n_tasks) a.queue = nullptr;   // one round
+    a.n_tasks = (int)n_tasks;
+    dim3 grid((unsigned)(a.queue ? a.resident : n_tasks)), block((unsigned)threads);
     if (lds_bytes > 64 * 1024) {   // opt in to the full 160 KiB of a CU, once per instantiation
         static std::atomic<uint64_t> raised{0};
         if (lds_opt_in_pending(raised)) {
+            // not the full 160 KiB: the kernels have a static word of LDS of their own (next_slot)
             hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
             if (e != hipSuccess) { raised = 0; return e; }
         }
     }
