@@ -35,6 +35,8 @@ CONFIGS = {
     "c3": (100_000, 20_000, 0.05, 20),
     "c5-shard": (125_000, 25_000, 0.02, 50),     # one GPU's 1/8 share of C5 (1M x 25k)
     "c4-shard": (12_500, 20_000, 0.05, 20),      # one GPU's 1/8 share of C3/C4 (what a rank of --gpus 8 holds)
+    "c4-shard2": (50_000, 20_000, 0.05, 20),     # ... of --gpus 2
+    "c4-shard4": (25_000, 20_000, 0.05, 20),     # ... of --gpus 4
 }
 HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
