@@ -604,10 +604,11 @@ template <typename T> struct Engine final : schpf_ctx {
 
     // Workgroup shape of the tile sweep.  One 1024-thread workgroup per CU with a 152 KiB window
     // (fewest stagings, longest row segments => least sliced-ELL padding) unless that leaves fewer
-    // than 64 (block, window) pairs per orientation; then the workgroup is halved (64 KiB windows,
-    // two workgroups per CU) until there are.  Measured on a 1/8 shard of C3 and on C2
-    // (SCHPF_MIN_PAIRS = 768 / 256 / 128 / 64): the large workgroup wins well below one task per
-    // CU, because both orientations share a launch and small windows cost padding and partials.
+    // than 256 (block, window) pairs per orientation; then the workgroup is halved (64 KiB windows,
+    // two or more workgroups per CU) until there are, down to 256 threads.  Measured with the graph /
+    // persistent launches of round 2 (profiles/r02/explore_c2_shapes.log): C2 (10k x 5k) 256-thread
+    // workgroups 24.6 k -> 26.7 k it/s in f64, -4 % per iteration in f32 (128 threads: +5 %, hence the
+    // floor); a 1/8 shard of C3 keeps the large workgroup in f64 (525 pairs) and halves it in f32 (-3 %).
     int cu_count = 256;
     int n_cu() const { return cu_count; }
     schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false) const
@@ -622,7 +623,7 @@ template <typename T> struct Engine final : schpf_ctx {
                 const int64_t wr = std::max<int64_t>(1, (int64_t)kb * 1024 / (int64_t)row_bytes);
                 const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
                 const int64_t windows = ((int64_t)n_minor + wr - 1) / wr;
-                if (blocks * windows >= env_int("SCHPF_MIN_PAIRS", 64) || wpb <= 2) break;
+                if (blocks * windows >= env_int("SCHPF_MIN_PAIRS", 256) || wpb <= 4) break;
                 wpb /= 2;
             }
         }
