@@ -675,7 +675,11 @@ template <typename T> struct Engine final : schpf_ctx {
                 const double per_row = (double)nnz / std::max(1, n_major) * (double)half_rows / std::max(1, n_minor);
                 const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
                 const int64_t windows = ((int64_t)n_minor + sh.win_rows - 1) / sh.win_rows;
-                if (half_rows >= 1 && per_row >= 16.0 && blocks * windows >= 1024) n_slots = 2;
+                // (the two-launch iteration of a row shard gains from it at a quarter of that: 1/8 of C3,
+                // 525 pairs, sweeps 2 x 70 -> 2 x 63 us)
+                // -- measured with the 1024-thread workgroup only (64 KiB windows halved lose: f32 1/8 shard +5 %)
+                if (wpb >= 12 && half_rows >= 1 && per_row >= 16.0 && blocks * windows >= (expect_sharded ? 256 : 1024))
+                    n_slots = 2;
             }
             if (n_slots >= 2 && sh.ring <= 1) {
                 const int slot_bytes = (int)((size_t)lds_kb * 1024 / (size_t)n_slots / 16 * 16);
