@@ -661,25 +661,41 @@ template <typename T> struct Engine final : schpf_ctx {
                 sh.win_rows = (int)sub_rows;
             }
         }
+        // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
+        // there are few (block, window) pairs (1/8 shard of C3: 1024 -> 256 tasks is 10 % faster:
+        // fewer partial rows to write and to sum, no ragged second round)
+        const int64_t full_rows = sh.ring > 1 ? (int64_t)sh.win_rows * (sh.ring - 1) : sh.win_rows;
+        const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
+        const int64_t windows = ((int64_t)n_minor + full_rows - 1) / full_rows;
+        // ... and half as many for an orientation with few blocks (the gene side of C3: 40 blocks of 512
+        // genes): 1024 tasks there are 26 window ranges per block = 26 partial rows per gene to write and
+        // to sum; 512 measured -3.5 % sweep, -15 % update time (profiles/r02/explore_tasks_per_side.log)
+        int dflt = blocks * windows >= 2048 ? (wpb >= 12 ? 1024 : 2048) : 256;
+        if (dflt >= 1024 && blocks < 64) dflt /= 2;
+        sh.target_tasks = env_int("SCHPF_TASKS", dflt);
+        sh.target_tasks = env_int(gene_side ? "SCHPF_TASKS_GENE" : "SCHPF_TASKS_CELL", sh.target_tasks);
         // Half-window schedule (plan.h): the window's LDS cut into two slots, refilled at the epoch boundary
-        // by the window kernel itself.  Chosen where it was measured to pay (BASELINE C3: -3 % sweep time in
-        // float64, -2 % in float32; profiles/r02/explore_half_window.log): rows with many nonzeros per
-        // half window (the lock-step loss is what it removes; with ~3 per half window, C5, the second
-        // barrier per window costs more: +2 %) on a problem with many (block, window) pairs (it loses
-        // 2-8 % on the one-round launches of C2 and of a 1/8 shard).  SCHPF_HALF = 0 / slots overrides.
+        // by the window kernel itself.  Chosen per orientation where it was measured to pay
+        // (profiles/r02/explore_half_window.log, explore_half_midsize.log):
+        //  * rows with many nonzeros per half window -- the lock-step loss is what it removes; with ~3 per
+        //    half window (C5) the second barrier per window costs more;
+        //  * the 1024-thread workgroup (64 KiB windows halved lose 5 %);
+        //  * tasks long enough to work ahead in: the horizon ends with the task and a task's first epoch
+        //    fills both slots.  >= 6 half windows per task in the one-launch iteration (C3 8 / 16: -2..3 %;
+        //    half of C3's cells 4 / 8: the cell side +1..4 % with it; 1/8: +2 %), >= 4 in the two-launch
+        //    iteration of a row shard (1/8 of C3: sweeps 2 x 70 -> 2 x 63 us).
+        // SCHPF_HALF = 0 / slots overrides.
         {
             const int half_env = env_int("SCHPF_HALF", -1);
             int n_slots = half_env >= 2 ? half_env : 0;
-            if (half_env < 0 && sh.ring <= 1) {
+            if (half_env < 0 && sh.ring <= 1 && wpb >= 12) {
                 const int64_t half_rows = ((int64_t)lds_kb * 512 - 64) / (int64_t)row_bytes;
-                const double per_row = (double)nnz / std::max(1, n_major) * (double)half_rows / std::max(1, n_minor);
-                const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
-                const int64_t windows = ((int64_t)n_minor + sh.win_rows - 1) / sh.win_rows;
-                // (the two-launch iteration of a row shard gains from it at a quarter of that: 1/8 of C3,
-                // 525 pairs, sweeps 2 x 70 -> 2 x 63 us)
-                // -- measured with the 1024-thread workgroup only (64 KiB windows halved lose: f32 1/8 shard +5 %)
-                if (wpb >= 12 && half_rows >= 1 && per_row >= 16.0 && blocks * windows >= (expect_sharded ? 256 : 1024))
-                    n_slots = 2;
+                if (half_rows >= 1) {
+                    const double per_row = (double)nnz / std::max(1, n_major) * (double)half_rows / std::max(1, n_minor);
+                    const int64_t half_windows = ((int64_t)n_minor + half_rows - 1) / half_rows;
+                    const int64_t per_task = half_windows * blocks / std::max(1, sh.target_tasks);   // plan.cpp: wpt
+                    if (per_row >= 16.0 && per_task >= (expect_sharded ? 4 : 6)) n_slots = 2;
+                }
             }
             if (n_slots >= 2 && sh.ring <= 1) {
                 const int slot_bytes = (int)((size_t)lds_kb * 1024 / (size_t)n_slots / 16 * 16);
@@ -692,19 +708,6 @@ template <typename T> struct Engine final : schpf_ctx {
                 }
             }
         }
-        // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
-        // there are few (block, window) pairs (1/8 shard of C3: 1024 -> 256 tasks is 10 % faster:
-        // fewer partial rows to write and to sum, no ragged second round)
-        const int64_t lds_rows = sh.ring > 1 ? (int64_t)sh.win_rows * (sh.ring - (sh.sync_stage == 1 ? 0 : 1)) : sh.win_rows;
-        const int64_t blocks = ((int64_t)n_major + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
-        const int64_t windows = ((int64_t)n_minor + lds_rows - 1) / lds_rows;
-        // ... and half as many for an orientation with few blocks (the gene side of C3: 40 blocks of 512
-        // genes): 1024 tasks there are 26 window ranges per block = 26 partial rows per gene to write and
-        // to sum; 512 measured -3.5 % sweep, -15 % update time (profiles/r02/explore_tasks_per_side.log)
-        int dflt = blocks * windows >= 2048 ? (wpb >= 12 ? 1024 : 2048) : 256;
-        if (dflt >= 1024 && blocks < 64) dflt /= 2;
-        sh.target_tasks = env_int("SCHPF_TASKS", dflt);
-        sh.target_tasks = env_int(gene_side ? "SCHPF_TASKS_GENE" : "SCHPF_TASKS_CELL", sh.target_tasks);
         // workgroups in flight: one 1024-thread (152 KiB) workgroup per CU, two of the smaller ones; both
         // orientations share a launch unless the iteration is sharded (two launches, schpf_hint_sharded)
         const int per_launch = n_cu() * (wpb >= 12 ? 1 : 2);
