@@ -34,6 +34,7 @@ CONFIGS = {
     "c2": (10_000, 5_000, 0.03, 10),
     "c3": (100_000, 20_000, 0.05, 20),
     "c5-shard": (125_000, 25_000, 0.02, 50),     # one GPU's 1/8 share of C5 (1M x 25k)
+    "c5": (1_000_000, 25_000, 0.02, 50),         # all of C5 on ONE GPU (nnz ~5e8: minutes of host-side generation)
     "c4-shard": (12_500, 20_000, 0.05, 20),      # one GPU's 1/8 share of C3/C4 (what a rank of --gpus 8 holds)
     "c4-shard2": (50_000, 20_000, 0.05, 20),     # ... of --gpus 2
     "c4-shard4": (25_000, 20_000, 0.05, 20),     # ... of --gpus 4
