@@ -569,7 +569,10 @@ template <typename T> struct Engine final : schpf_ctx {
     void build_tiles_device(const int32_t *row, const int32_t *col, const float *val, bool packed_ok)
     {
         const double t0 = now_s();
-        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N, true);
+        int ranges[2] = {0, 0}, half[2] = {-1, -1};
+        if (!choose_ranges(ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
+        const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
+                               sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         bool rc_sorted = true, cr_sorted = true;
         schpf::coo_order_flags(nnz, row, col, rc_sorted, cr_sorted);
         DevBuf d_row, d_col, d_val;
@@ -611,10 +614,10 @@ template <typename T> struct Engine final : schpf_ctx {
     // floor); a 1/8 shard of C3 keeps the large workgroup in f64 (525 pairs) and halves it in f32 (-3 %).
     int cu_count = 256;
     int n_cu() const { return cu_count; }
-    schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false) const
+    void pick_workgroup(int n_major, int n_minor, int &wpb, int &lds_kb) const
     {
-        int wpb = env_int("SCHPF_WPB", 0);
-        int lds_kb = env_int("SCHPF_LDS_KB", 0);
+        wpb = env_int("SCHPF_WPB", 0);
+        lds_kb = env_int("SCHPF_LDS_KB", 0);
         const size_t row_bytes = (size_t)KP * sizeof(T);
         if (!wpb) {
             wpb = 16;
@@ -628,6 +631,61 @@ template <typename T> struct Engine final : schpf_ctx {
             }
         }
         if (!lds_kb) lds_kb = wpb >= 12 ? 152 : 64;
+    }
+    // Task ranges of both orientations of the one-launch iteration from the list-schedule model of
+    // plan.h choose_task_ranges (big problems with the 1024-thread workgroup on both sides; knobs that fix
+    // task counts or schedules by hand switch it off).  Constants from C3 on an MI355X: a workgroup works
+    // through ~1.7e11 / (K sizeof(T)) nonzeros per second (K = 20: 1.06e9 f64, 2.1e9 f32; measured 1.07 /
+    // 1.9), a partial row is written and read back at ~3.5 TB/s, a task costs 3 us beside its nonzeros
+    // (SCHPF_TASK_US; swept 2-16: 2-4 pick one range per cell block and 18 per gene block at C3 f64, the
+    // fastest measured).  Against the former fixed counts (profiles/r02/explore_task_ranges.log), per
+    // iteration: C3 f64 (6, 13) -> (1, 18) ranges -2.4 %, C3 f32 (3, 13) -> (3, 11) -3.3 %, half of C3's
+    // cells -7.5 %, a quarter -3 %, the C5 share -1..2 % (f64) / -4 % (f32).
+    bool choose_ranges(int ranges[2], int half[2]) const
+    {
+        if (expect_sharded || !env_int("SCHPF_RANGES", 1) || !env_int("SCHPF_DUAL", 1)) return false;
+        for (const char *knob : {"SCHPF_TASKS", "SCHPF_TASKS_CELL", "SCHPF_TASKS_GENE", "SCHPF_RING"})
+            if (getenv(knob) && *getenv(knob)) return false;
+        const int half_env = env_int("SCHPF_HALF", -1);
+        if (half_env >= 2) return false;
+        const size_t row_bytes = (size_t)KP * sizeof(T);
+        const int n_maj[2] = {N, G}, n_min[2] = {G, N};
+        int64_t blocks[2], half_windows[2];
+        bool half_ok[2];
+        double partial_seconds[2];
+        for (int s = 0; s < 2; ++s) {
+            int wpb, lds_kb;
+            pick_workgroup(n_maj[s], n_min[s], wpb, lds_kb);
+            if (wpb < 12) return false;
+            const int64_t half_rows = ((int64_t)lds_kb * 512 - 64) / (int64_t)row_bytes;
+            if (half_rows < 1) return false;
+            blocks[s] = ((int64_t)n_maj[s] + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
+            half_windows[s] = ((int64_t)n_min[s] + half_rows - 1) / half_rows;
+            const double per_row = (double)nnz / std::max(1, n_maj[s]) * (double)half_rows / std::max(1, n_min[s]);
+            half_ok[s] = half_env != 0 && per_row >= 16.0;
+            partial_seconds[s] = 2.0 * (double)n_maj[s] * (double)row_bytes / 3.5e12;
+        }
+        const int resident = n_cu();
+        // only where a launch is several rounds of workgroups: smaller problems keep the rules of tile_shape
+        if (blocks[0] * half_windows[0] + blocks[1] * half_windows[1] < 16 * (int64_t)resident) return false;
+        const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, (double)nnz, resident,
+                                                               1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
+                                                               partial_seconds,
+                                                               6, 1.12, 32);
+        if (c.ranges[0] <= 0 || c.ranges[1] <= 0) return false;
+        for (int s = 0; s < 2; ++s) { ranges[s] = c.ranges[s]; half[s] = c.half[s] ? 1 : 0; }
+        if (env_int("SCHPF_VERBOSE", 0))
+            fprintf(stderr, "[schpf_hip]   task ranges from the list-schedule model: cell %d (%s), gene %d (%s), %.3f ms\n",
+                    ranges[0], half[0] ? "half windows" : "windows", ranges[1], half[1] ? "half windows" : "windows",
+                    c.seconds * 1e3);
+        return true;
+    }
+    schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false, int ranges = 0,
+                                int force_half = -1) const
+    {
+        int wpb, lds_kb;
+        pick_workgroup(n_major, n_minor, wpb, lds_kb);
+        const size_t row_bytes = (size_t)KP * sizeof(T);
         schpf::TileShape sh;
         sh.lpc = LPC;
         sh.waves_per_block = wpb;
@@ -688,7 +746,8 @@ template <typename T> struct Engine final : schpf_ctx {
         {
             const int half_env = env_int("SCHPF_HALF", -1);
             int n_slots = half_env >= 2 ? half_env : 0;
-            if (half_env < 0 && sh.ring <= 1 && wpb >= 12) {
+            if (force_half >= 0) n_slots = force_half ? 2 : 0;
+            else if (half_env < 0 && sh.ring <= 1 && wpb >= 12) {
                 const int64_t half_rows = ((int64_t)lds_kb * 512 - 64) / (int64_t)row_bytes;
                 if (half_rows >= 1) {
                     const double per_row = (double)nnz / std::max(1, n_major) * (double)half_rows / std::max(1, n_minor);
@@ -712,6 +771,7 @@ template <typename T> struct Engine final : schpf_ctx {
         // orientations share a launch unless the iteration is sharded (two launches, schpf_hint_sharded)
         const int per_launch = n_cu() * (wpb >= 12 ? 1 : 2);
         sh.slots = env_int("SCHPF_TASK_ROUNDING", 1) ? (expect_sharded ? per_launch : per_launch / 2) : 0;
+        sh.ranges = ranges;
         return sh;
     }
 
@@ -719,7 +779,10 @@ template <typename T> struct Engine final : schpf_ctx {
     // then uploaded one after the other on the context's stream
     void build_tiles(const int32_t *row, const int32_t *col, const float *val)
     {
-        const schpf::TileShape sh_c = tile_shape(N, G), sh_g = tile_shape(G, N, true);
+        int ranges[2] = {0, 0}, half[2] = {-1, -1};
+        if (!choose_ranges(ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
+        const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
+                               sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         std::exception_ptr err;
         double secs_gene = 0.0;
         std::thread side([&] {

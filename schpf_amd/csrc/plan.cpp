@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <stdexcept>
 #include <thread>
@@ -397,11 +398,12 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     int64_t wpt = 1;
     if (target_tasks > 0) wpt = std::max<int64_t>(1, (int64_t)W * P.n_blocks / target_tasks);
     wpt = std::min<int64_t>(wpt, W);
+    if (shape.ranges > 0) wpt = std::max<int64_t>(1, ((int64_t)W + shape.ranges - 1) / shape.ranges);
     // Small problems: a launch of slightly more workgroups than the GPU runs at once takes two rounds
     // where one would do (an 1/8 shard of C3: 275 tasks of 2 windows on 256 CUs = 4 window-times;
     // 175 tasks of 3 windows = 3).  With `slots` = workgroups this orientation can have in flight,
     // between one and two rounds' worth of tasks are regrouped into one round.
-    if (shape.slots > 0) {
+    if (shape.slots > 0 && shape.ranges <= 0) {
         const int64_t tasks = ((W + wpt - 1) / wpt) * P.n_blocks;
         if (tasks > shape.slots && tasks < 2 * (int64_t)shape.slots && P.n_blocks <= shape.slots) {
             const int64_t ranges = std::max<int64_t>(1, shape.slots / P.n_blocks);
@@ -482,6 +484,59 @@ void xcd_launch_order(const TilePlanHost *const *plans, int n_plans, int n_xcd, 
         }
     for (int x = 0; x < n_xcd; ++x)
         for (size_t q = 0; q < queue[(size_t)x].size(); ++q) order[q * (size_t)n_xcd + (size_t)x] = queue[(size_t)x][q];
+}
+
+RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windows[2], const bool half_ok[2],
+                               double nnz, int resident, double nnz_per_second, double task_seconds,
+                               const double partial_seconds[2], int min_half_per_task, double window_penalty,
+                               int max_ranges)
+{
+    struct Pool { int64_t n_full, n_last; double d_full, d_last; bool half; };
+    auto pool = [&](int s, int r, Pool &p) {
+        // the schedule this orientation would get with r ranges, and its tasks
+        const bool half = half_ok[s] && half_windows[s] / r >= min_half_per_task;
+        const int64_t W = half ? half_windows[s] : (half_windows[s] + 1) / 2;
+        if (r > W) return false;
+        const int64_t wpt = (W + r - 1) / r;
+        if ((W + wpt - 1) / wpt != r) return false;            // r is not a range count the planner produces
+        const double per_window = nnz / (double)(blocks[s] * W) * (half ? 1.0 : window_penalty) / nnz_per_second;
+        p.half = half;
+        p.n_full = blocks[s] * (r - 1);
+        p.n_last = blocks[s];
+        p.d_full = (double)wpt * per_window + task_seconds;
+        p.d_last = (double)(W - wpt * (r - 1)) * per_window + task_seconds;
+        return true;
+    };
+    RangeChoice best{{0, 0}, {false, false}, 1e300};
+    std::vector<double> durations, load;
+    for (int rc = 1; rc <= max_ranges; ++rc) {
+        Pool pc;
+        if (!pool(0, rc, pc)) continue;
+        for (int rg = 1; rg <= max_ranges; ++rg) {
+            Pool pg;
+            if (!pool(1, rg, pg)) continue;
+            const int64_t n_tasks = pc.n_full + pc.n_last + pg.n_full + pg.n_last;
+            if (n_tasks > 16 * (int64_t)resident) continue;
+            // list schedule, longest first, on `resident` identical workgroups (a heap of their loads)
+            durations.clear();
+            durations.insert(durations.end(), (size_t)pc.n_full, pc.d_full);
+            durations.insert(durations.end(), (size_t)pc.n_last, pc.d_last);
+            durations.insert(durations.end(), (size_t)pg.n_full, pg.d_full);
+            durations.insert(durations.end(), (size_t)pg.n_last, pg.d_last);
+            std::sort(durations.begin(), durations.end(), std::greater<double>());
+            load.assign((size_t)resident, 0.0);
+            std::make_heap(load.begin(), load.end(), std::greater<double>());      // min-heap
+            for (double d : durations) {
+                std::pop_heap(load.begin(), load.end(), std::greater<double>());
+                load.back() += d;
+                std::push_heap(load.begin(), load.end(), std::greater<double>());
+            }
+            const double span = *std::max_element(load.begin(), load.end());
+            const double total = span + rc * partial_seconds[0] + rg * partial_seconds[1];
+            if (total < best.seconds) best = RangeChoice{{rc, rg}, {pc.half, pg.half}, total};
+        }
+    }
+    return best;
 }
 
 // with P.steps known: task work / merged-launch order, where every (block, wave)'s entries start

@@ -176,8 +176,27 @@ struct TileShape {
     int ring = 1, slot_bytes = 0;
     int sync_stage = 0;        // ring mode: 1 = the HALF-WINDOW schedule above (ring >= 2 then)
     int slots = 0;          // workgroups of this orientation the GPU runs at once (0: unknown); see tile_plan_begin
+    int ranges = 0;         // > 0: window ranges (tasks) per block, fixed by the caller (choose_task_ranges);
+                            // target_tasks and the rounding by `slots` are then not consulted
     bool bank_order = true, allow_packed = true;
 };
+// How many window ranges (tasks per block) each orientation of a ONE-LAUNCH iteration should have.  The
+// merged launch runs its tasks longest first on `resident` workgroups that draw from one list, so the
+// launch lasts as long as a list schedule of the two task pools: with few tasks per workgroup the
+// leftover of the last round costs up to a whole task (C3 f32: 294 + 260 tasks on 256 workgroups ran
+// 1.37 x the balanced time), with many the per-task costs (a first window, table rows, partial rows that
+// the update kernel has to sum) take over.  Model, per orientation s: blocks[s] x ranges tasks, each of
+// ceil(windows / ranges) windows (the last range shorter), a window = nnz / (blocks x windows) nonzeros
+// at `nnz_per_second` per workgroup, + task_seconds per task; + partial_seconds[s] per range for the
+// partial rows.  `windows` are counted in the unit the schedule would use (half windows where
+// half_ok[s] and a task keeps >= min_half_per_task of them; whole windows cost window_penalty more work).
+// Exhaustive over 1..max_ranges for both; returns the pair with the shortest modelled iteration.
+struct RangeChoice { int ranges[2]; bool half[2]; double seconds; };
+RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windows[2], const bool half_ok[2],
+                               double nnz, int resident, double nnz_per_second, double task_seconds,
+                               const double partial_seconds[2], int min_half_per_task, double window_penalty,
+                               int max_ranges);
+
 // Launch order (slot -> task) of the tile sweep over one or two plans' tasks that keeps the tasks
 // reading the SAME window range of the minor table on ONE XCD at the same time: an XCD's 32 compute
 // units then stage the same table rows within a short time of each other and all but the first copy
