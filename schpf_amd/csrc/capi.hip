@@ -643,7 +643,7 @@ template <typename T> struct Engine final : schpf_ctx {
     // cells -7.5 %, a quarter -3 %, the C5 share -1..2 % (f64) / -4 % (f32).
     bool choose_ranges(int ranges[2], int half[2]) const
     {
-        if (expect_sharded || !env_int("SCHPF_RANGES", 1) || !env_int("SCHPF_DUAL", 1)) return false;
+        if (!env_int("SCHPF_RANGES", 1) || (!expect_sharded && !env_int("SCHPF_DUAL", 1))) return false;
         for (const char *knob : {"SCHPF_TASKS", "SCHPF_TASKS_CELL", "SCHPF_TASKS_GENE", "SCHPF_RING"})
             if (getenv(knob) && *getenv(knob)) return false;
         const int half_env = env_int("SCHPF_HALF", -1);
@@ -671,7 +671,7 @@ template <typename T> struct Engine final : schpf_ctx {
         const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, (double)nnz, resident,
                                                                1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
                                                                partial_seconds,
-                                                               6, 1.12, 32);
+                                                               expect_sharded ? 4 : 6, 1.12, 32, expect_sharded);
         if (c.ranges[0] <= 0 || c.ranges[1] <= 0) return false;
         for (int s = 0; s < 2; ++s) { ranges[s] = c.ranges[s]; half[s] = c.half[s] ? 1 : 0; }
         if (env_int("SCHPF_VERBOSE", 0))

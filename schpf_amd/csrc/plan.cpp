@@ -489,7 +489,7 @@ void xcd_launch_order(const TilePlanHost *const *plans, int n_plans, int n_xcd, 
 RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windows[2], const bool half_ok[2],
                                double nnz, int resident, double nnz_per_second, double task_seconds,
                                const double partial_seconds[2], int min_half_per_task, double window_penalty,
-                               int max_ranges)
+                               int max_ranges, bool separate_launches)
 {
     struct Pool { int64_t n_full, n_last; double d_full, d_last; bool half; };
     auto pool = [&](int s, int r, Pool &p) {
@@ -509,31 +509,45 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
     };
     RangeChoice best{{0, 0}, {false, false}, 1e300};
     std::vector<double> durations, load;
-    for (int rc = 1; rc <= max_ranges; ++rc) {
-        Pool pc;
-        if (!pool(0, rc, pc)) continue;
-        for (int rg = 1; rg <= max_ranges; ++rg) {
-            Pool pg;
-            if (!pool(1, rg, pg)) continue;
-            const int64_t n_tasks = pc.n_full + pc.n_last + pg.n_full + pg.n_last;
-            if (n_tasks > 16 * (int64_t)resident) continue;
-            // list schedule, longest first, on `resident` identical workgroups (a heap of their loads)
-            durations.clear();
-            durations.insert(durations.end(), (size_t)pc.n_full, pc.d_full);
-            durations.insert(durations.end(), (size_t)pc.n_last, pc.d_last);
-            durations.insert(durations.end(), (size_t)pg.n_full, pg.d_full);
-            durations.insert(durations.end(), (size_t)pg.n_last, pg.d_last);
-            std::sort(durations.begin(), durations.end(), std::greater<double>());
-            load.assign((size_t)resident, 0.0);
-            std::make_heap(load.begin(), load.end(), std::greater<double>());      // min-heap
-            for (double d : durations) {
-                std::pop_heap(load.begin(), load.end(), std::greater<double>());
-                load.back() += d;
-                std::push_heap(load.begin(), load.end(), std::greater<double>());
+    // list schedule, longest first, on `resident` identical workgroups (a heap of their loads)
+    auto span_of = [&](const Pool *pools, int n_pools) {
+        durations.clear();
+        for (int i = 0; i < n_pools; ++i) {
+            durations.insert(durations.end(), (size_t)pools[i].n_full, pools[i].d_full);
+            durations.insert(durations.end(), (size_t)pools[i].n_last, pools[i].d_last);
+        }
+        std::sort(durations.begin(), durations.end(), std::greater<double>());
+        load.assign((size_t)resident, 0.0);
+        std::make_heap(load.begin(), load.end(), std::greater<double>());      // min-heap
+        for (double d : durations) {
+            std::pop_heap(load.begin(), load.end(), std::greater<double>());
+            load.back() += d;
+            std::push_heap(load.begin(), load.end(), std::greater<double>());
+        }
+        return *std::max_element(load.begin(), load.end());
+    };
+    if (separate_launches) {   // one launch per orientation: each pool has the device to itself
+        best.seconds = 0.0;
+        for (int s = 0; s < 2; ++s) {
+            double best_s = 1e300;
+            for (int r = 1; r <= max_ranges; ++r) {
+                Pool p;
+                if (!pool(s, r, p) || p.n_full + p.n_last > 16 * (int64_t)resident) continue;
+                const double total = span_of(&p, 1) + r * partial_seconds[s];
+                if (total < best_s) { best_s = total; best.ranges[s] = r; best.half[s] = p.half; }
             }
-            const double span = *std::max_element(load.begin(), load.end());
-            const double total = span + rc * partial_seconds[0] + rg * partial_seconds[1];
-            if (total < best.seconds) best = RangeChoice{{rc, rg}, {pc.half, pg.half}, total};
+            best.seconds += best_s;
+        }
+        return best;
+    }
+    for (int rc = 1; rc <= max_ranges; ++rc) {
+        Pool pools[2];
+        if (!pool(0, rc, pools[0])) continue;
+        for (int rg = 1; rg <= max_ranges; ++rg) {
+            if (!pool(1, rg, pools[1])) continue;
+            if (pools[0].n_full + pools[0].n_last + pools[1].n_full + pools[1].n_last > 16 * (int64_t)resident) continue;
+            const double total = span_of(pools, 2) + rc * partial_seconds[0] + rg * partial_seconds[1];
+            if (total < best.seconds) best = RangeChoice{{rc, rg}, {pools[0].half, pools[1].half}, total};
         }
     }
     return best;

@@ -191,11 +191,12 @@ struct TileShape {
 // partial rows.  `windows` are counted in the unit the schedule would use (half windows where
 // half_ok[s] and a task keeps >= min_half_per_task of them; whole windows cost window_penalty more work).
 // Exhaustive over 1..max_ranges for both; returns the pair with the shortest modelled iteration.
+// separate_launches: the two-launch iteration of a row shard -- each orientation scheduled on its own.
 struct RangeChoice { int ranges[2]; bool half[2]; double seconds; };
 RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windows[2], const bool half_ok[2],
                                double nnz, int resident, double nnz_per_second, double task_seconds,
                                const double partial_seconds[2], int min_half_per_task, double window_penalty,
-                               int max_ranges);
+                               int max_ranges, bool separate_launches);
 
 // Launch order (slot -> task) of the tile sweep over one or two plans' tasks that keeps the tasks
 // reading the SAME window range of the minor table on ONE XCD at the same time: an XCD's 32 compute
