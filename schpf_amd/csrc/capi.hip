@@ -570,7 +570,7 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         const double t0 = now_s();
         int ranges[2] = {0, 0}, half[2] = {-1, -1};
-        if (!choose_ranges(ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
+        if (!choose_ranges(row, col, ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
         const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
                                sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         bool rc_sorted = true, cr_sorted = true;
@@ -641,7 +641,7 @@ template <typename T> struct Engine final : schpf_ctx {
     // fastest measured).  Against the former fixed counts (profiles/r02/explore_task_ranges.log), per
     // iteration: C3 f64 (6, 13) -> (1, 18) ranges -2.4 %, C3 f32 (3, 13) -> (3, 11) -3.3 %, half of C3's
     // cells -7.5 %, a quarter -3 %, the C5 share -1..2 % (f64) / -4 % (f32).
-    bool choose_ranges(int ranges[2], int half[2]) const
+    bool choose_ranges(const int32_t *row, const int32_t *col, int ranges[2], int half[2]) const
     {
         if (!env_int("SCHPF_RANGES", 1) || (!expect_sharded && !env_int("SCHPF_DUAL", 1))) return false;
         for (const char *knob : {"SCHPF_TASKS", "SCHPF_TASKS_CELL", "SCHPF_TASKS_GENE", "SCHPF_RING"})
@@ -668,7 +668,13 @@ template <typename T> struct Engine final : schpf_ctx {
         const int resident = n_cu();
         // only where a launch is several rounds of workgroups: smaller problems keep the rules of tile_shape
         if (blocks[0] * half_windows[0] + blocks[1] * half_windows[1] < 16 * (int64_t)resident) return false;
-        const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, (double)nnz, resident,
+        // where the nonzeros sit: a skewed matrix has heavy blocks (the planted benchmark matrix: one range per
+        // cell block -- the uniform model's choice -- doubles the iteration, its heaviest block runs last)
+        std::vector<double> share[2];
+        const int64_t stride = std::max<int64_t>(1, nnz / 4000000);   // ~4 M samples per orientation: a few ms
+        share[0] = schpf::block_shares(nnz, row, N, (64 / LPC) * 16, stride);
+        share[1] = schpf::block_shares(nnz, col, G, (64 / LPC) * 16, stride);
+        const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, share, (double)nnz, resident,
                                                                1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
                                                                partial_seconds,
                                                                expect_sharded ? 4 : 6, 1.12, 32, expect_sharded);
@@ -780,7 +786,7 @@ template <typename T> struct Engine final : schpf_ctx {
     void build_tiles(const int32_t *row, const int32_t *col, const float *val)
     {
         int ranges[2] = {0, 0}, half[2] = {-1, -1};
-        if (!choose_ranges(ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
+        if (!choose_ranges(row, col, ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
         const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
                                sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         std::exception_ptr err;

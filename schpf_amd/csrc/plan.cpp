@@ -486,25 +486,65 @@ void xcd_launch_order(const TilePlanHost *const *plans, int n_plans, int n_xcd, 
         for (size_t q = 0; q < queue[(size_t)x].size(); ++q) order[q * (size_t)n_xcd + (size_t)x] = queue[(size_t)x][q];
 }
 
+std::vector<double> block_shares(int64_t nnz, const int32_t *major, int n_major, int rows_per_block, int64_t stride)
+{
+    stride = std::max<int64_t>(1, stride);
+    const int64_t n_samples = (nnz + stride - 1) / stride;
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(host_threads(), 16), n_samples / 65536 + 1));
+    std::vector<std::vector<int32_t>> local((size_t)nth, std::vector<int32_t>((size_t)n_major, 0));
+    parallel_for(n_samples, nth, [&](int64_t b, int64_t e, int t) {
+        int32_t *h = local[(size_t)t].data();
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t m = major[i * stride];
+            if (m >= 0 && m < n_major) ++h[m];          // indices are validated elsewhere
+        }
+    });
+    std::vector<int32_t> &count = local[0];
+    int32_t longest = 0;
+    for (int m = 0; m < n_major; ++m) {
+        int32_t c = 0;
+        for (int t = 0; t < nth; ++t) c += local[(size_t)t][(size_t)m];
+        count[(size_t)m] = c;
+        longest = std::max(longest, c);
+    }
+    // rows by decreasing length = a histogram of lengths walked from the top
+    std::vector<int64_t> rows_of_length((size_t)longest + 1, 0);
+    for (int m = 0; m < n_major; ++m) ++rows_of_length[(size_t)count[(size_t)m]];
+    const int64_t n_blocks = ((int64_t)n_major + rows_per_block - 1) / rows_per_block;
+    std::vector<double> share((size_t)n_blocks, 0.0);
+    int64_t placed = 0;
+    double total = 0.0;
+    for (int64_t len = longest; len >= 0; --len) {
+        int64_t n = rows_of_length[(size_t)len];
+        while (n > 0) {
+            const int64_t b = placed / rows_per_block;
+            const int64_t take = std::min<int64_t>(n, (b + 1) * rows_per_block - placed);
+            share[(size_t)b] += (double)take * (double)len;
+            total += (double)take * (double)len;
+            placed += take;
+            n -= take;
+        }
+    }
+    if (total > 0.0)
+        for (double &v : share) v /= total;
+    return share;
+}
+
 RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windows[2], const bool half_ok[2],
+                               const std::vector<double> block_share[2],
                                double nnz, int resident, double nnz_per_second, double task_seconds,
                                const double partial_seconds[2], int min_half_per_task, double window_penalty,
                                int max_ranges, bool separate_launches)
 {
-    struct Pool { int64_t n_full, n_last; double d_full, d_last; bool half; };
+    struct Pool { int64_t n_tasks; int s; int64_t r, wpt, W; double per_nnz; bool half; };
     auto pool = [&](int s, int r, Pool &p) {
-        // the schedule this orientation would get with r ranges, and its tasks
+        // the schedule this orientation would get with r ranges
         const bool half = half_ok[s] && half_windows[s] / r >= min_half_per_task;
         const int64_t W = half ? half_windows[s] : (half_windows[s] + 1) / 2;
         if (r > W) return false;
         const int64_t wpt = (W + r - 1) / r;
         if ((W + wpt - 1) / wpt != r) return false;            // r is not a range count the planner produces
-        const double per_window = nnz / (double)(blocks[s] * W) * (half ? 1.0 : window_penalty) / nnz_per_second;
-        p.half = half;
-        p.n_full = blocks[s] * (r - 1);
-        p.n_last = blocks[s];
-        p.d_full = (double)wpt * per_window + task_seconds;
-        p.d_last = (double)(W - wpt * (r - 1)) * per_window + task_seconds;
+        p = Pool{blocks[s] * r, s, r, wpt, W, (half ? 1.0 : window_penalty) / nnz_per_second, half};
         return true;
     };
     RangeChoice best{{0, 0}, {false, false}, 1e300};
@@ -513,8 +553,14 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
     auto span_of = [&](const Pool *pools, int n_pools) {
         durations.clear();
         for (int i = 0; i < n_pools; ++i) {
-            durations.insert(durations.end(), (size_t)pools[i].n_full, pools[i].d_full);
-            durations.insert(durations.end(), (size_t)pools[i].n_last, pools[i].d_last);
+            const Pool &p = pools[i];
+            const std::vector<double> &share = block_share[p.s];
+            for (int64_t b = 0; b < blocks[p.s]; ++b) {
+                const double block_nnz = nnz * (share.empty() ? 1.0 / (double)blocks[p.s] : share[(size_t)b]);
+                const double per_window = block_nnz / (double)p.W * p.per_nnz;
+                durations.insert(durations.end(), (size_t)(p.r - 1), (double)p.wpt * per_window + task_seconds);
+                durations.push_back((double)(p.W - p.wpt * (p.r - 1)) * per_window + task_seconds);
+            }
         }
         std::sort(durations.begin(), durations.end(), std::greater<double>());
         load.assign((size_t)resident, 0.0);
@@ -532,7 +578,7 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
             double best_s = 1e300;
             for (int r = 1; r <= max_ranges; ++r) {
                 Pool p;
-                if (!pool(s, r, p) || p.n_full + p.n_last > 16 * (int64_t)resident) continue;
+                if (!pool(s, r, p) || p.n_tasks > 16 * (int64_t)resident) continue;
                 const double total = span_of(&p, 1) + r * partial_seconds[s];
                 if (total < best_s) { best_s = total; best.ranges[s] = r; best.half[s] = p.half; }
             }
@@ -545,7 +591,7 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
         if (!pool(0, rc, pools[0])) continue;
         for (int rg = 1; rg <= max_ranges; ++rg) {
             if (!pool(1, rg, pools[1])) continue;
-            if (pools[0].n_full + pools[0].n_last + pools[1].n_full + pools[1].n_last > 16 * (int64_t)resident) continue;
+            if (pools[0].n_tasks + pools[1].n_tasks > 16 * (int64_t)resident) continue;
             const double total = span_of(pools, 2) + rc * partial_seconds[0] + rg * partial_seconds[1];
             if (total < best.seconds) best = RangeChoice{{rc, rg}, {pools[0].half, pools[1].half}, total};
         }

@@ -186,14 +186,20 @@ struct TileShape {
 // leftover of the last round costs up to a whole task (C3 f32: 294 + 260 tasks on 256 workgroups ran
 // 1.37 x the balanced time), with many the per-task costs (a first window, table rows, partial rows that
 // the update kernel has to sum) take over.  Model, per orientation s: blocks[s] x ranges tasks, each of
-// ceil(windows / ranges) windows (the last range shorter), a window = nnz / (blocks x windows) nonzeros
+// ceil(windows / ranges) windows (the last range shorter), a window of block b = its share of nnz / windows
 // at `nnz_per_second` per workgroup, + task_seconds per task; + partial_seconds[s] per range for the
 // partial rows.  `windows` are counted in the unit the schedule would use (half windows where
 // half_ok[s] and a task keeps >= min_half_per_task of them; whole windows cost window_penalty more work).
 // Exhaustive over 1..max_ranges for both; returns the pair with the shortest modelled iteration.
 // separate_launches: the two-launch iteration of a row shard -- each orientation scheduled on its own.
 struct RangeChoice { int ranges[2]; bool half[2]; double seconds; };
+// Shares of the nonzeros per block of `rows_per_block` rows taken in order of decreasing length, estimated
+// from every `stride`-th index of the COO (threaded histogram + counting sort).
+std::vector<double> block_shares(int64_t nnz, const int32_t *major, int n_major, int rows_per_block, int64_t stride);
+// block_share[s][b] = share of the nonzeros that block b of orientation s holds (rows go to blocks by
+// decreasing length, so a skewed matrix has a few heavy blocks whose tasks decide the tail; empty = uniform).
 RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windows[2], const bool half_ok[2],
+                               const std::vector<double> block_share[2],
                                double nnz, int resident, double nnz_per_second, double task_seconds,
                                const double partial_seconds[2], int min_half_per_task, double window_penalty,
                                int max_ranges, bool separate_launches);
