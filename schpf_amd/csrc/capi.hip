@@ -666,8 +666,10 @@ template <typename T> struct Engine final : schpf_ctx {
             partial_seconds[s] = 2.0 * (double)n_maj[s] * (double)row_bytes / 3.5e12;
         }
         const int resident = n_cu();
-        // only where a launch is several rounds of workgroups: smaller problems keep the rules of tile_shape
-        if (blocks[0] * half_windows[0] + blocks[1] * half_windows[1] < 16 * (int64_t)resident) return false;
+        // only where a launch is several rounds of workgroups (1/8 of C3: -4 % in one launch, +-0 in two): smaller
+        // problems keep the rules of tile_shape
+        if (blocks[0] * half_windows[0] + blocks[1] * half_windows[1] < env_int("SCHPF_RANGES_MIN", 6) * (int64_t)resident)
+            return false;
         // where the nonzeros sit: a skewed matrix has heavy blocks (the planted benchmark matrix: one range per
         // cell block -- the uniform model's choice -- doubles the iteration, its heaviest block runs last)
         std::vector<double> share[2];
