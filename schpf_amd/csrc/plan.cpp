@@ -589,10 +589,13 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
     for (int rc = 1; rc <= max_ranges; ++rc) {
         Pool pools[2];
         if (!pool(0, rc, pools[0])) continue;
+        // the loss pass sweeps the cell-side plan alone, at about a PHI sweep's cost per nonzero, once per
+        // check interval (every 10th iteration by default): its tail counts a tenth
+        const double loss_share = 0.1 * span_of(pools, 1);
         for (int rg = 1; rg <= max_ranges; ++rg) {
             if (!pool(1, rg, pools[1])) continue;
             if (pools[0].n_tasks + pools[1].n_tasks > 16 * (int64_t)resident) continue;
-            const double total = span_of(pools, 2) + rc * partial_seconds[0] + rg * partial_seconds[1];
+            const double total = span_of(pools, 2) + loss_share + rc * partial_seconds[0] + rg * partial_seconds[1];
             if (total < best.seconds) best = RangeChoice{{rc, rg}, {pools[0].half, pools[1].half}, total};
         }
     }
