@@ -578,7 +578,7 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
             double best_s = 1e300;
             for (int r = 1; r <= max_ranges; ++r) {
                 Pool p;
-                if (!pool(s, r, p) || p.n_tasks > 16 * (int64_t)resident) continue;
+                if (!pool(s, r, p) || (r > 1 && p.n_tasks > 16 * (int64_t)resident)) continue;
                 const double total = span_of(&p, 1) + r * partial_seconds[s];
                 if (total < best_s) { best_s = total; best.ranges[s] = r; best.half[s] = p.half; }
             }
@@ -594,7 +594,10 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
         const double loss_share = 0.1 * span_of(pools, 1);
         for (int rg = 1; rg <= max_ranges; ++rg) {
             if (!pool(1, rg, pools[1])) continue;
-            if (pools[0].n_tasks + pools[1].n_tasks > 16 * (int64_t)resident) continue;
+            // many blocks are many tasks already: one range per block of such an orientation is always a
+            // candidate, more ranges only while the orientation stays under 16 tasks per workgroup
+            if ((rc > 1 && pools[0].n_tasks > 16 * (int64_t)resident) || (rg > 1 && pools[1].n_tasks > 16 * (int64_t)resident))
+                continue;
             const double total = span_of(pools, 2) + loss_share + rc * partial_seconds[0] + rg * partial_seconds[1];
             if (total < best.seconds) best = RangeChoice{{rc, rg}, {pools[0].half, pools[1].half}, total};
         }
