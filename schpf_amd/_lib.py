@@ -123,6 +123,12 @@ def load():
         raise SchpfHipError(
             "libschpf_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # Multi-process / multi-GPU work (RCCL, sharing device memory between processes) needs dmabuf IPC
+    # on this driver stack: without HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment BEFORE the HSA runtime
+    # initialises, RCCL fails with `hipIpcGetMemHandle: invalid argument`.  Set here, ahead of the dlopen
+    # below, so that fit(devices=[...]), run_trials_pool(devices=...), the CLI and bench.py all get it;
+    # a value the caller exported wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     HIP_RUNTIME = _hip_runtime_path()
     # RCCL follows the HIP runtime: the copy next to it (torch/lib or /opt/rocm/lib) unless overridden
     if not os.environ.get("SCHPF_RCCL_PATH"):

@@ -283,9 +283,13 @@ template <typename T> struct Engine final : schpf_ctx {
     int pending_init = 0;  // 0 none, 1 dense accumulators, 2 chunk partials
     // n iterations captured as one hipGraph (schpf_steps): the state is device-resident and nothing on
     // the host changes between two loss checks, so a fit replays one graph per check interval
-    hipGraphExec_t graph_exec = nullptr;
-    unsigned graph_flags = 0;
-    int graph_n = 0;
+    // The sum-of-beta buffers swap roles every iteration (beta_parity counts the swaps mod 2) and a
+    // capture bakes the pointers in, so a graph is keyed by (flags, n, parity at its start): one cached
+    // graph per parity.  A stretch with an odd count (check_freq = 5: graph of 4 + one eager iteration)
+    // starts its calls at alternating parities and alternates between the two.
+    struct CachedGraph { hipGraphExec_t exec = nullptr; unsigned flags = 0; int n = 0; };
+    CachedGraph graphs[2];
+    int beta_parity = 0;
     bool eager_since_upload = false;   // one eager iteration has run on this plan (kernel attributes are set)
     // small problems: the update kernels sum the other side's per-block column sums themselves and the
     // two reduce launches of an iteration are skipped; s_theta / s_beta are then brought up to date
@@ -329,8 +333,33 @@ template <typename T> struct Engine final : schpf_ctx {
     void hint_sharded(int on) override { expect_sharded = on != 0; }   // a, c, bp, dp are kernel arguments of the captured launches
     void drop_graph()
     {
-        if (graph_exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-        graph_n = 0;
+        for (CachedGraph &g : graphs) {
+            if (g.exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            g.n = 0;
+        }
+    }
+    // the graph of `count` (even) iterations issued by `body` for the current parity: cached or captured now
+    template <typename F> hipGraphExec_t graph_for(unsigned key_flags, int count, F &&body)
+    {
+        CachedGraph &g = graphs[beta_parity & 1];
+        if (g.exec && g.flags == key_flags && g.n == count) return g.exec;
+        if (g.exec) { (void)hipStreamSynchronize(stream); (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.n = 0; }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        try {
+            body(count);   // runs the host side of `count` iterations (an even number of swaps) without executing them
+        } catch (...) {
+            (void)hipStreamEndCapture(stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        HIPCHK(hipStreamEndCapture(stream, &graph));
+        const hipError_t e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIPCHK(e);
+        g.flags = key_flags;
+        g.n = count;
+        return g.exec;
     }
 
     // n iterations of schpf_step.  From the second call on with the same (flags, n) they are one
@@ -345,26 +374,10 @@ template <typename T> struct Engine final : schpf_ctx {
         int done = 0;
         if (graphable && n >= 2) {
             const int even = n & ~1;
-            if (!graph_exec || graph_flags != flags_ || graph_n != even) {
-                drop_graph();
-                hipGraph_t graph = nullptr;
-                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                try {
-                    for (int i = 0; i < even; ++i) { step_local(flags_); step_finish(flags_); }
-                } catch (...) {
-                    (void)hipStreamEndCapture(stream, &graph);
-                    if (graph) (void)hipGraphDestroy(graph);
-                    throw;
-                }
-                HIPCHK(hipStreamEndCapture(stream, &graph));
-                const hipError_t e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                HIPCHK(e);
-                graph_flags = flags_;
-                graph_n = even;
-                // the capture ran the host side of `even` iterations (pointer swaps) without executing them
-            }
-            HIPCHK(hipGraphLaunch(graph_exec, stream));
+            hipGraphExec_t exec = graph_for(flags_, even, [&](int count) {
+                for (int i = 0; i < count; ++i) { step_local(flags_); step_finish(flags_); }
+            });
+            HIPCHK(hipGraphLaunch(exec, stream));
             done = even;
         }
         for (; done < n; ++done) { step_local(flags_); step_finish(flags_); }
@@ -403,25 +416,8 @@ template <typename T> struct Engine final : schpf_ctx {
                                pending_init == 0 && eager_since_upload && !dirty_theta && !dirty_beta && !freeze;
         if (graphable && n >= 2) {
             const int even = n & ~1;
-            if (!graph_exec || graph_flags != (base | 0x80000000u) || graph_n != even) {
-                drop_graph();
-                hipGraph_t graph = nullptr;
-                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                try {
-                    iterate(even);
-                } catch (...) {
-                    (void)hipStreamEndCapture(stream, &graph);
-                    if (graph) (void)hipGraphDestroy(graph);
-                    throw;
-                }
-                HIPCHK(hipStreamEndCapture(stream, &graph));
-                const hipError_t e = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                HIPCHK(e);
-                graph_flags = base | 0x80000000u;
-                graph_n = even;
-            }
-            HIPCHK(hipGraphLaunch(graph_exec, stream));
+            hipGraphExec_t exec = graph_for(base | 0x80000000u, even, iterate);
+            HIPCHK(hipGraphLaunch(exec, stream));
             done = even;
         }
         iterate(n - done);
@@ -1300,7 +1296,7 @@ template <typename T> struct Engine final : schpf_ctx {
         };
         if (cells_first) { cell_update(); gene_update(); }   // minibatch order: theta first, beta from the NEW theta
         else { gene_update(); cell_update(); }
-        if (!freeze) std::swap(s_beta.p, s_beta_next.p);
+        if (!freeze) { std::swap(s_beta.p, s_beta_next.p); beta_parity ^= 1; }
         if (fuse) sums_stale = true;
         if (pending_init == 1) dense_cell.release();
         pending_init = 0;

@@ -81,8 +81,9 @@ class DeviceCAVI(object):
         self.close()
 
     # -------------------------------------------------------------------- inputs
-    def upload(self, X):
-        """X: scipy coo_matrix-like with .row, .col, .data (ncells x ngenes)."""
+    def upload(self, X, warn=True):
+        """X: scipy coo_matrix-like with .row, .col, .data (ncells x ngenes).  warn=False: the caller
+        issues rounding_warning() itself (a helper thread must not touch the warnings machinery)."""
         if tuple(X.shape) != (self.ncells, self.ngenes):
             raise ValueError("X has shape %s, engine was created for %s"
                              % (tuple(X.shape), (self.ncells, self.ngenes)))
@@ -94,12 +95,17 @@ class DeviceCAVI(object):
         _lib.check(self._lib.schpf_upload_coo(self._h, data.shape[0], _p(row), _p(col), _p(data),
                                               _VAL_KINDS[data.dtype]))
         self.nnz = int(data.shape[0])
+        if warn:
+            self.rounding_warning(stacklevel=3)
+
+    def rounding_warning(self, stacklevel=2):
+        """Warn (on the calling thread) if the last upload rounded values of X.data to float32."""
         info = self.upload_info()
         if info["rounded"]:
             import warnings
             warnings.warn("%d of %d values of X.data are not exactly representable in float32 and were "
                           "rounded (relative error <= 6e-8); counts are stored as float32 on the device"
-                          % (info["rounded"], info["nnz"]), RuntimeWarning, stacklevel=2)
+                          % (info["rounded"], info["nnz"]), RuntimeWarning, stacklevel=stacklevel)
 
     def upload_info(self):
         """{'nnz', 'rounded' (values rounded to float32), 'zeros' (explicitly stored), 'packed'}."""

@@ -21,8 +21,12 @@ def loss_function_for_data(loss_function, X):
     return functools.partial(loss_function, X=X)
 
 
-def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_kwargs={}):
+def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_kwargs={}, device=None):
     """Loss of held-out cells `X` after projecting them onto the model being trained.
+
+    `device` (an addition to the reference's signature): HIP device the held-out cells live on;
+    default $SCHPF_DEVICE or 0, like project().  The returned function has a `.close()` that
+    releases the engine it keeps between checks.
 
     Returns f(*, a, ap, bp, c, cp, dp, eta, beta, **ignored): it copies the
     hyperparameters and gene distributions into a private scHPF, runs project(X,
@@ -35,6 +39,9 @@ def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_k
     pmodel = scHPF(nfactors=nfactors, **model_kwargs)
     if not hasattr(X, "row"):
         X = X.tocoo()
+    import os
+    if device is None:
+        device = int(os.environ.get("SCHPF_DEVICE", "0"))
     held = {}    # the held-out cells stay on the device between checks: one upload, one pair of plans
 
     def _projection_loss_function(*, a, ap, bp, c, cp, dp, eta, beta, **kwargs):
@@ -53,10 +60,13 @@ def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_k
         if eng is None or eng.dtype != dtype or "engine" in proj_kwargs:
             eng = proj_kwargs.get("engine")
             if eng is None:
-                eng = DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype)
+                old = held.pop("engine", None)
+                if old is not None:
+                    old.close()
+                eng = DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device)
                 eng.upload(X)
                 held["engine"] = eng
-        pmodel.project(X, replace=True, **dict(proj_kwargs, engine=eng))
+        pmodel.project(X, replace=True, **dict(proj_kwargs, engine=eng, device=device))
 
         if getattr(loss_function, "func", loss_function) is mean_negative_pois_llh:   # also a functools.partial of it
             # the engine holds exactly the state project() just returned: evaluate there (one scalar back)
@@ -65,6 +75,11 @@ def projection_loss_function(loss_function, X, nfactors, model_kwargs={}, proj_k
                              dp=pmodel.dp, xi=pmodel.xi, eta=pmodel.eta, theta=pmodel.theta,
                              beta=pmodel.beta)
 
+    def close():
+        eng = held.pop("engine", None)
+        if eng is not None:
+            eng.close()
+    _projection_loss_function.close = close
     return _projection_loss_function
 
 

@@ -159,11 +159,10 @@ class _EarlyUpload(object):
             eng = None
             try:
                 eng = DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device)
-                import warnings
-                with warnings.catch_warnings(record=True) as caught:
-                    warnings.simplefilter("always")
-                    eng.upload(X)
-                self._out["engine"], self._out["warnings"] = eng, caught
+                # warnings.catch_warnings mutates process-global state and is not thread-safe: the
+                # worker never touches it; result() issues the upload's warning on the caller's thread
+                eng.upload(X, warn=False)
+                self._out["engine"] = eng
             except BaseException as exc:     # re-raised on the caller's thread
                 if eng is not None:
                     eng.close()
@@ -175,9 +174,7 @@ class _EarlyUpload(object):
         self._thread.join()
         if "error" in self._out:
             raise self._out["error"]
-        import warnings
-        for w in self._out.get("warnings", ()):      # e.g. "values were rounded to float32"
-            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        self._out["engine"].rounding_warning(stacklevel=3)      # "values were rounded to float32"
         return self._out["engine"]
 
     def abandon(self):

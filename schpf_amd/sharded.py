@@ -149,17 +149,48 @@ class ThreadedShards(object):
         self.comm = comm
         uid = DeviceCAVI.comm_unique_id() if comm == "rccl" else None
 
+        # Two phases.  comm_init is a collective: a rank that raised before reaching it (an upload
+        # validation error, out of memory, an empty shard) would leave the others blocked inside
+        # ncclCommInitRank for ever.  So every shard is built and uploaded first, the errors are
+        # gathered, and the communicator is only joined when all shards exist.
         def build(rank):
             lo, hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
+            if hi <= lo:
+                raise ValueError("shard %d of %d would hold no cells (%d cells for %d devices)"
+                                 % (rank, self.world, self.ncells, self.world))
             sub, keep = take_rows(X, lo, hi)
             self.keep[rank] = keep
             eng = make_engine(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
-            eng.hint_sharded()
-            eng.upload(sub)
-            if uid is not None:
-                eng.comm_init(uid, rank, self.world)     # collective: all threads arrive here
+            try:
+                eng.hint_sharded()
+                eng.upload(sub)
+            except BaseException:
+                eng.close()
+                raise
             return eng
-        self.engines = self._each(build)
+
+        def attempt(fn):
+            def run(rank):
+                try:
+                    return fn(rank), None
+                except BaseException as exc:
+                    return None, exc
+            return run
+        self.engines = []
+        try:
+            built = self._each(attempt(build))
+            self.engines = [e for e, _ in built if e is not None]
+            errors = [exc for _, exc in built if exc is not None]
+            if errors:
+                raise errors[0]
+            if uid is not None:   # collective: all threads arrive, every shard exists
+                joined = self._each(attempt(lambda r: self.engines[r].comm_init(uid, r, self.world)))
+                errors = [exc for _, exc in joined if exc is not None]
+                if errors:
+                    raise errors[0]
+        except BaseException:
+            self.close()
+            raise
         if comm != "rccl":
             self._views = [e.exchange if hasattr(e, "exchange") else exchange_tensor_of(e, d)
                            for e, d in zip(self.engines, self.devices)]
@@ -190,8 +221,12 @@ class ThreadedShards(object):
         self._each(lambda r: self.engines[r].init_phi_host(Xphi_data[self.keep[r]]))
 
     def init_phi_device(self, seed):
-        # cells differ between shards, so one seed gives independent draws per nonzero
-        self._each(lambda r: self.engines[r].init_phi_device(seed))
+        # the device generator is keyed by (seed, LOCAL cell, gene) and every shard numbers its cells
+        # from 0: one seed for all would give local cell i of every shard the same responsibilities for
+        # a gene.  Each rank gets its own stream of the generator (seed mixed with the rank).
+        def rank_seed(r):
+            return (int(seed) + 0x9E3779B97F4A7C15 * (r + 1)) & (2 ** 64 - 1)
+        self._each(lambda r: self.engines[r].init_phi_device(rank_seed(r)))
 
     def steps(self, n, freeze_genes=False, simultaneous=False, cells_first=False):
         if cells_first:

@@ -29,7 +29,7 @@ def _default_device():
     return int(os.environ.get("SCHPF_DEVICE", "0"))
 
 
-def _loss_plumbing(X, nfactors, check_freq, vcells, vX, loss_function, single_process):
+def _loss_plumbing(X, nfactors, check_freq, vcells, vX, loss_function, single_process, device=None):
     """Which loss `fit` should use: None = the device's own training loss (the reference's
     default, mean_negative_pois_llh on X); otherwise a host callable as in the reference."""
     if vcells is not None:
@@ -43,7 +43,7 @@ def _loss_plumbing(X, nfactors, check_freq, vcells, vX, loss_function, single_pr
         proj_kwargs = dict(reinit=False, min_iter=1, max_iter=min(10, check_freq),
                            check_freq=check_freq + 1, verbose=False)
         return loss_function, ls.projection_loss_function(loss_function, vcells, nfactors,
-                                                          proj_kwargs=proj_kwargs)
+                                                          proj_kwargs=proj_kwargs, device=device)
     if default and (vX is None or vX is X):
         return loss_function, None
     return loss_function, ls.loss_function_for_data(loss_function, X if vX is None else vX)
@@ -61,8 +61,8 @@ def run_trials(X, nfactors, ntrials=5, min_iter=30, max_iter=1000, check_freq=10
     ncells, ngenes = X.shape
     if ngenes >= 20000:
         print(_GENE_WARNING.format(ngenes))
-    raw_loss, data_loss_function = _loss_plumbing(X, nfactors, check_freq, vcells, vX, loss_function, False)
     device = _default_device() if device is None else device
+    raw_loss, data_loss_function = _loss_plumbing(X, nfactors, check_freq, vcells, vX, loss_function, False, device)
     batched = batchsize is not None and 1 < batchsize <= ncells
 
     engine = None
@@ -106,6 +106,8 @@ def run_trials(X, nfactors, ntrials=5, min_iter=30, max_iter=1000, check_freq=10
     finally:
         if engine is not None:
             engine.close()
+        if hasattr(data_loss_function, "close"):      # the held-out cells' engine (validation loss)
+            data_loss_function.close()
     if return_all:
         order = np.argsort(losses)
         ordered = [models[i] for i in order]
@@ -132,7 +134,7 @@ def run_trials_pool(X, nfactors, ntrials=5, njobs=0, max_threads=None, min_iter=
     batched = batchsize is not None and 1 < batchsize <= X.shape[0]
 
     def fit_all(K, device, count):
-        _, dlf = _loss_plumbing(X, K, check_freq, vcells, vX, loss_function, True)
+        _, dlf = _loss_plumbing(X, K, check_freq, vcells, vX, loss_function, True, device)
         engine = None
         if not batched:
             engine = DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype, device=device)
@@ -152,6 +154,8 @@ def run_trials_pool(X, nfactors, ntrials=5, njobs=0, max_threads=None, min_iter=
         finally:
             if engine is not None:
                 engine.close()
+            if hasattr(dlf, "close"):
+                dlf.close()
         return out
 
     # restarts of one K are dealt to the devices in contiguous shares

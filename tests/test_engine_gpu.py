@@ -837,7 +837,10 @@ def test_steps_call_equals_single_steps_bitwise(amd, oracle, dtype, flags, plan_
             for n in ("xi", "theta", "eta", "beta"):
                 (s0, r0), (s1, r1) = one.get_gamma(n), many.get_gamma(n)
                 assert np.array_equal(s0, s1) and np.array_equal(r0, r1), n
-        for count in (1, 4, 4, 4, 5, 2):
+        # (.., 5, 5, 4, 4, 5, 4): odd counts leave the sum-of-beta buffers swapped on the host, so the
+        # graph of 4 is captured at one parity and must not be replayed at the other (round-2 advisor
+        # finding: with simultaneous=True the replay read the sums of one iteration earlier)
+        for count in (1, 4, 4, 4, 5, 2, 5, 5, 4, 4, 5, 4):
             for _ in range(count):
                 one.step(**flags)
             many.steps(count, **flags)
