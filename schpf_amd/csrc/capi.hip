@@ -320,7 +320,7 @@ template <typename T> struct Engine final : schpf_ctx {
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
         be_s.alloc((size_t)G * K * s); be_r.alloc((size_t)G * K * s);
-        // + TABLE_PAD zero bytes: the ring sweep copies whole 1 KiB pieces and may read past the last row
+        // + TABLE_PAD zero bytes: slack behind the last row for whole-piece copies
         for (DevBuf *b : {&th_exp, &th_e, &th_log}) b->alloc((size_t)N * KP * s + TABLE_PAD, true, stream);
         for (DevBuf *b : {&be_exp, &be_e, &be_log}) b->alloc((size_t)G * KP * s + TABLE_PAD, true, stream);
         exchange_buf.alloc(((size_t)G * K + K) * s, true, stream);
@@ -479,9 +479,12 @@ template <typename T> struct Engine final : schpf_ctx {
             if (want_tile && nv > 7) continue;                 // the tile sweeps are instantiated for <= 7 vectors
             if (want_tile) cost = (nv * 16 <= 112 || force_lpc) ? 0 : 1 << 20;   // first that fits
             else cost = nv * std::max(1, lpc / 4);
+            // only instantiated pairs (kernels.h): the planner's own choices always are, a forced LPC may not be
+            if (!(want_tile ? schpf::tile_combo_ok(nv, lpc) : schpf::gather_combo_ok(nv, lpc))) continue;
             if (cost < best_cost) { best_cost = cost; best_lpc = lpc; best_nv = nv; }
         }
-        if (!best_lpc) throw std::invalid_argument("SCHPF_LPC must be one of 1,2,4,8,16 and fit nfactors");
+        if (!best_lpc) throw std::invalid_argument("SCHPF_LPC must be one of 1,2,4,8,16, fit nfactors and be an "
+                                                   "instantiated shape (kernels.h tile_combo_ok / gather_combo_ok)");
         LPC = best_lpc; NV = best_nv; KL = NV * vec; KP = KL * LPC;
     }
 
@@ -640,7 +643,7 @@ template <typename T> struct Engine final : schpf_ctx {
     bool choose_ranges(const int32_t *row, const int32_t *col, int ranges[2], int half[2]) const
     {
         if (!env_int("SCHPF_RANGES", 1) || (!expect_sharded && !env_int("SCHPF_DUAL", 1))) return false;
-        for (const char *knob : {"SCHPF_TASKS", "SCHPF_TASKS_CELL", "SCHPF_TASKS_GENE", "SCHPF_RING"})
+        for (const char *knob : {"SCHPF_TASKS", "SCHPF_TASKS_CELL", "SCHPF_TASKS_GENE"})
             if (getenv(knob) && *getenv(knob)) return false;
         const int half_env = env_int("SCHPF_HALF", -1);
         if (half_env >= 2) return false;
@@ -697,32 +700,6 @@ template <typename T> struct Engine final : schpf_ctx {
         sh.bank_order = env_int("SCHPF_BANK_ORDER", 1) != 0;
         sh.allow_packed = env_int("SCHPF_PACK", 1) != 0;
         sh.win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
-        // Ring schedule (plan.h) when a ring slot still holds several nonzeros per row: slots of 2 KiB per
-        // wave (every wave issues two 1 KiB copies per epoch), as many as fit the workgroup's LDS
-        // (5 x 32 KiB = all 160 KiB of the CU for a 1024-thread workgroup; at most 8).  Sparse x wide problems
-        // (about a nonzero per row and slot) would spend their time at epoch barriers: window mode.
-        // Opt-in (SCHPF_RING >= 3): measured at BASELINE C3 the ring schedule fills 0.80-0.85 of the
-        // step slots against the window schedule's 0.68 and still loses 8 % (f64) / 15 % (f32): a
-        // barrier every ~7 steps instead of every ~30 costs more SIMD occupancy around the barrier than
-        // the padding it saves (profiles/r02/explore_ring_schedule.log).
-        const int ring_env = env_int("SCHPF_RING", 0);
-        if (ring_env > 1 && !schpf::ring_schedule_compiled())
-            throw std::invalid_argument("SCHPF_RING: this build has no ring schedule (it is compiled with "
-                                        "-DSCHPF_WITH_RING, tools/devbuild.sh); unknown to the shipped library");
-        if (ring_env != 0 && ring_env != 1) {
-            const int lds_total = (wpb >= 12 && !env_int("SCHPF_LDS_KB", 0)) ? 160 : lds_kb;
-            const int slot_kb = 2 * wpb;                  // the kernel copies two 1 KiB pieces per wave and epoch
-            int ring = std::min(lds_total / slot_kb, 8);
-            if (ring_env > 1) ring = std::min(ring, ring_env);
-            const int64_t sub_rows = ((int64_t)slot_kb * 1024 - 64) / (int64_t)row_bytes;
-            const double per_row = (double)nnz / std::max(1, n_major) * (double)sub_rows / std::max(1, n_minor);
-            if (ring >= 3 && sub_rows >= 1 && (int64_t)ring * slot_kb * 64 <= 65536 &&
-                (ring_env > 1 || per_row >= (double)env_int("SCHPF_RING_MIN_NNZ", 6))) {
-                sh.ring = ring;
-                sh.slot_bytes = slot_kb * 1024;
-                sh.win_rows = (int)sub_rows;
-            }
-        }
         // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
         // there are few (block, window) pairs (1/8 shard of C3: 1024 -> 256 tasks is 10 % faster:
         // fewer partial rows to write and to sum, no ragged second round)
@@ -1477,7 +1454,7 @@ extern "C" {
 const char *schpf_last_error(void) { return g_err.c_str(); }
 const char *schpf_version(void)
 {
-    return schpf::ring_schedule_compiled() ? "schpf_hip 0.2 (gfx950) +ring" : "schpf_hip 0.2 (gfx950)";
+    return "schpf_hip 0.3 (gfx950)";
 }
 
 int schpf_device_count(int *count)
@@ -1755,7 +1732,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         schpf::TileShape sh;
         sh.lpc = lpc; sh.waves_per_block = waves_per_block; sh.win_rows = win_rows; sh.target_tasks = target_tasks;
         sh.row_slots = 10;   // 160-byte table rows
-        sh.ring = ring < 0 ? -ring : ring; sh.sync_stage = ring < 0 ? 1 : 0; sh.slot_bytes = slot_bytes;
+        sh.ring = ring < 0 ? -ring : ring; sh.sync_stage = sh.ring > 1 ? 1 : 0; sh.slot_bytes = slot_bytes;
         sh.allow_packed = getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true;
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, false, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
@@ -1766,8 +1743,6 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                 int64_t off = P.task_wave_off[(size_t)t * wpb + v];
                 for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                     const int steps = P.steps[((size_t)b * wpb + v) * W + w];
-                    if (P.ring > 1 && !P.sync_stage && steps != P.steps[((size_t)b * wpb) * W + w])
-                        throw std::logic_error("ring plan: the waves of a block disagree on an epoch's steps");
                     for (int p = 0; p < steps; ++p)
                         for (int grp = 0; grp < gpw; ++grp)
                             for (int u = 0; u < 2; ++u) {

@@ -70,8 +70,19 @@ template <typename T> struct UpdateArgs {
     double *colsum_part;        // [nblocks, K]
 };
 
-// whether the sweep objects were compiled with the opt-in ring schedule (-DSCHPF_WITH_RING)
-bool ring_schedule_compiled();
+// (vectors per lane, lanes per row) pairs the sweeps are instantiated for (sweep_impl.h SCHPF_DISPATCH*)
+inline bool tile_combo_ok(int nv, int lpc)
+{
+    if (lpc == 1) return nv >= 1 && nv <= 7;
+    if (lpc == 2 || lpc == 4 || lpc == 8) return nv >= 4 && nv <= 7;
+    return lpc == 16 && nv == 4;
+}
+inline bool gather_combo_ok(int nv, int lpc)
+{
+    if (lpc == 4) return (nv >= 1 && nv <= 8) || nv == 10;
+    if (lpc == 8) return nv == 6 || nv == 7 || nv == 8 || nv == 10;
+    return lpc == 16 && nv >= 6 && nv <= 8;
+}
 
 template <typename T>
 hipError_t launch_sweep(const SweepArgs<T> &a, int nv, int lpc, int mode, int64_t n_waves, hipStream_t st);

@@ -358,17 +358,16 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     P.row_slots = shape.row_slots;
     int win_rows = shape.win_rows;
     if (shape.ring > 1) {
-        if (shape.sync_stage < 0 || shape.sync_stage > 1) throw std::invalid_argument("sync_stage is 0 or 1");
-        if (shape.ring < (shape.sync_stage == 1 ? 2 : 3)) throw std::invalid_argument("too few ring slots");
-        if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % 16 ||
-            (!shape.sync_stage && shape.slot_bytes % (1024 * waves_per_block)))
-            throw std::invalid_argument("slot_bytes must hold a row (and, for the asynchronous ring, be a multiple "
-                                        "of 1 KiB per wave)");
+        // the only multi-slot schedule shipped is the half-window one (slots refilled AT the epoch
+        // boundary); the asynchronous ring of round 2 lives in the history
+        if (shape.sync_stage != 1) throw std::invalid_argument("multi-slot plans need sync_stage = 1");
+        if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % 16)
+            throw std::invalid_argument("slot_bytes must hold a row and be a multiple of 16");
         P.ring = shape.ring;
-        P.sync_stage = shape.sync_stage;
-        P.look = shape.sync_stage == 1 ? shape.ring - 1 : shape.ring - 2;
+        P.sync_stage = 1;
+        P.look = shape.ring - 1;
         P.slot16 = shape.slot_bytes / 16;
-        win_rows = (P.slot16 - 4) / shape.row_slots;   // the last 64 bytes of a slot stay free (kernel: counters)
+        win_rows = (P.slot16 - 4) / shape.row_slots;   // the last 64 bytes of a slot stay free
     }
     if (win_rows < 1) throw std::invalid_argument("win_rows must be positive");
     if ((int64_t)std::max(P.ring, 1) * std::max<int64_t>(P.slot16, (int64_t)win_rows * shape.row_slots) > 65536)
@@ -695,12 +694,11 @@ void tile_plan_report(const TilePlanHost &P)
             (long long)wave_steps, wave_steps ? (double)wave_steps / (double)barrier_steps : 0.0);
 }
 
-// Ring-mode schedule of one block (plan.h): for every epoch e the steps T_e all waves run, and for
+// Half-window schedule of one block (plan.h): for every epoch e the steps T_e each WAVE runs, and for
 // every lane how many of its row's nonzeros (in minor order) it has consumed BEFORE epoch e.
-//   start[g * (W + 1) + e], e = 0..W;  T[e]
-// Greedy: T_e = ceil(max over lanes of the nonzeros still owed up to sub-window e, / 2), rounded up
-// to a multiple of 4; every lane
-// then takes min(2 T_e, what lies inside the readable horizon min(e + ring - 1, task end)).
+//   start[g * (W + 1) + e], e = 0..W;  T[wave * W + e]
+// Greedy: T_e = ceil(max over the wave's lanes of the nonzeros still owed up to sub-window e, / 2);
+// every lane then takes min(2 T_e, what lies inside the readable horizon min(e + ring, task end)).
 // cnt_below(g, bound) = number of the lane's nonzeros with minor < bound * win_rows.
 template <typename CntBelow>
 static void ring_schedule_block(const TilePlanHost &P, int64_t b, CntBelow cnt_below, int32_t *start, uint32_t *T)
@@ -711,17 +709,12 @@ static void ring_schedule_block(const TilePlanHost &P, int64_t b, CntBelow cnt_b
     for (int e = 0; e < W; ++e) {
         const int w1 = (int)std::min<int64_t>((e / wpt + 1) * wpt, W);   // end of the task e belongs to
         const int hor = std::min(e + P.look + 1, w1);
-        // asynchronous ring: one T_e for the workgroup (its waves meet only through the slot counters),
-        // rounded up to the depth of the kernel's entry prefetch ring (4): an epoch then starts with
-        // its first entries in ring slots 0..3 and the prefetch distance survives the boundary.  The
-        // extra steps are not lost: rows with nonzeros inside the horizon work ahead in them.
-        // Half-window schedule: the waves meet at the barrier anyway, every wave has its own T_e.
-        const int span = P.sync_stage ? P.gpw : gpb;
+        const int span = P.gpw;   // the waves meet at the barrier anyway: every wave has its own T_e
         for (int g0 = 0; g0 < gpb; g0 += span) {
             int32_t need = 0;
             for (int g = g0; g < g0 + span; ++g) need = std::max(need, cnt_below(b, g, e + 1) - done[(size_t)g]);
-            const uint32_t Te = P.sync_stage ? (uint32_t)((need + 1) / 2) : (uint32_t)(((need + 1) / 2 + 3) / 4 * 4);
-            for (int v = g0 / P.gpw; v < (g0 + span) / P.gpw; ++v) T[(size_t)v * W + e] = Te;
+            const uint32_t Te = (uint32_t)((need + 1) / 2);
+            T[(size_t)(g0 / P.gpw) * W + e] = Te;
             for (int g = g0; g < g0 + span; ++g) {
                 start[(size_t)g * (W + 1) + e] = done[(size_t)g];
                 const int32_t avail = cnt_below(b, g, hor) - done[(size_t)g];

@@ -125,33 +125,27 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 //    at a barrier per window.  A row's nonzeros per window are Poisson-distributed, so the
 //    workgroup moves at the pace of the fullest of its rows in every window (measured at
 //    BASELINE C3: 0.68 of the slots carry nonzeros).  Kept for sparse x wide problems where a
-//    ring slot would hold a nonzero or two per row.
+//    slot would hold a nonzero or two per row.
 //
-//  * RING mode (ring >= 3): the LDS is a ring of `ring` slots of slot16 * 16 bytes; a "window" is
-//    now a SUB-window of win_rows = slot rows, sub-window s lives in slot s mod ring.  The
-//    workgroup advances in EPOCHS, one per sub-window: during epoch e the slots hold sub-windows
-//    e .. e+ring-2 (readable) while e+ring-1 is copied in asynchronously.  An epoch lasts T_e
-//    steps for EVERY wave of the block, T_e = what the row furthest behind needs to finish
-//    sub-window e (rounded up to a multiple of 4, the depth of the kernel's entry prefetch); a row
-//    that has finished it spends the remaining steps on its nonzeros of the sub-windows ahead (up
-//    to e+ring-2, never beyond its task).  Rows that fall behind in one
-//    sub-window have usually worked ahead before: at C3 0.88-0.91 of the slots carry nonzeros,
-//    and the staging copy never stalls the compute.  steps[] then holds T_e for every wave.
+//  * HALF-WINDOW schedule (ring >= 2, sync_stage = 1): the LDS is `ring` slots of slot16 * 16 bytes; a
+//    "window" is now a SUB-window of win_rows = slot rows, sub-window s lives in slot s mod ring.  The
+//    workgroup advances in EPOCHS, one per sub-window; all slots are readable during an epoch and are
+//    refilled AT the epoch boundary by the window schedule's own exposed copy (only the slot the
+//    last epoch's own sub-window had).  A row that has finished the epoch's own sub-window works
+//    ahead in up to ring - 1 slots (never beyond its task); every wave has its own step count per
+//    epoch.  With two slots of half a window the workgroup still stages exactly the bytes of the
+//    window schedule, meets at twice as many barriers, and the kernel is the window kernel with a
+//    different staging range; 0.87 of the slots carry nonzeros at C3 against 0.76.
 //
-//  * HALF-WINDOW schedule (ring >= 2, sync_stage): the ring schedule with few, large slots that
-//    are refilled AT the epoch boundary by the window schedule's own exposed copy (every slot is
-//    readable during an epoch, a row works ahead in up to ring - 1 slots).  With two slots of half
-//    a window the workgroup still stages exactly the bytes of the window schedule, meets at twice as
-//    many barriers, and the kernel is the window kernel with a different staging range; the
-//    schedule evens out half of the lock-step loss (simulated fill 0.80-0.83 against 0.68).
+// (Round 2 also built an ASYNCHRONOUS ring -- five small slots, copies under the compute, no barrier --
+// which was 8-13 % slower; it is not in the product sources any more: DESIGN.md 9, git history.)
 struct TilePlanHost {
     int n_major = 0, n_minor = 0;
     int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
     int win_rows = 0, n_windows = 0, windows_per_task = 0;
-    int ring = 1, slot16 = 0;             // ring mode: slots in the LDS ring, 16-byte units per slot
-    int look = 0;                         // ring mode: sub-windows beyond the epoch's own a row may work ahead in
-    int sync_stage = 0;                   // ring mode: 0 = asynchronous ring; 1 = slots refilled AT the epoch boundary (all
-                                          // slots readable, look = ring - 1, every wave its own step counts)
+    int ring = 1, slot16 = 0;             // half-window schedule: slots in the LDS, 16-byte units per slot
+    int look = 0;                         // ... sub-windows beyond the epoch's own a row may work ahead in (ring - 1)
+    int sync_stage = 0;                   // ... 1 whenever ring > 1 (slots refilled AT the epoch boundary)
     int row_slots = 0;                    // 16-byte units per table row (KP * sizeof(T) / 16)
     int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
     bool packed = false;                  // 8-byte entries {idx0|idx1<<16, cnt0|cnt1<<16} instead of 16-byte
@@ -168,13 +162,13 @@ struct TilePlanHost {
 };
 
 // Shape of a tile plan.  row_slots: 16-byte units per table row (KP * sizeof(T) / 16).
-// ring <= 1: window mode with win_rows rows per window.  ring >= 3: ring mode, slot_bytes per ring
-// slot (win_rows is then derived: slot_bytes / row bytes).  bank_order: deal the nonzeros of a
+// ring <= 1: window mode with win_rows rows per window.  ring >= 2 (with sync_stage = 1): half-window
+// schedule, slot_bytes per slot (win_rows is then derived: slot_bytes / row bytes).  bank_order: deal the nonzeros of a
 // segment to the steps in the LDS-bank-aware order (false = minor order).
 struct TileShape {
     int lpc = 1, waves_per_block = 16, win_rows = 1, target_tasks = 0, row_slots = 1;
     int ring = 1, slot_bytes = 0;
-    int sync_stage = 0;        // ring mode: 1 = the HALF-WINDOW schedule above (ring >= 2 then)
+    int sync_stage = 0;        // 1 with ring >= 2: the HALF-WINDOW schedule above
     int slots = 0;          // workgroups of this orientation the GPU runs at once (0: unknown); see tile_plan_begin
     int ranges = 0;         // > 0: window ranges (tasks) per block, fixed by the caller (choose_task_ranges);
                             // target_tasks and the rounding by `slots` are then not consulted
@@ -219,13 +213,8 @@ void xcd_launch_order(const TilePlanHost *const *plans, int n_plans, int n_xcd, 
 void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                      int n_major, int n_minor, const TileShape &shape, bool keep_order, TilePlanHost &out);
 
-// Step slots a (block, wave, window) occupies in the entry stream: ring mode pads every epoch to a
-// multiple of the kernel's prefetch-ring depth (4), so that the ring runs on across epoch
-// boundaries with every step in its slot (the padding steps are loaded, never executed).
-inline int64_t tile_stored_steps(const TilePlanHost &P, int steps)
-{
-    return P.ring > 1 && !P.sync_stage ? (int64_t)((steps + 3) / 4 * 4) : (int64_t)steps;
-}
+// Step slots a (block, wave, window) occupies in the entry stream
+inline int64_t tile_stored_steps(const TilePlanHost &, int steps) { return (int64_t)steps; }
 
 // LDS position (16-byte units) of minor row m: shared by both builders and the test hook
 inline uint32_t tile_off16(const TilePlanHost &P, int32_t m)

@@ -70,7 +70,7 @@ __global__ void fill_i64_kernel(int64_t n, int64_t v, int64_t *__restrict__ out)
 
 struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
-    int ring, slot16, wpt, look, sync_stage;
+    int ring, slot16, wpt, look;
 };
 
 // LDS position of minor row m in 16-byte units (plan.h tile_off16)
@@ -131,7 +131,6 @@ __global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const i
                                                             unsigned *__restrict__ steps32, int32_t *__restrict__ start,
                                                             int *__restrict__ err)
 {
-    __shared__ int red[16];
     const int64_t b = blockIdx.x;
     const int gi = threadIdx.x;                       // lane group of the block; blockDim.x = gpb rounded up to waves
     const bool owner = gi < g.gpb;
@@ -156,22 +155,9 @@ __global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const i
         int need = (int)(c_need - r0) - done;
         // maximum over the sweep kernel's wave (gpw lane groups, a power of two <= 64) ...
         for (int m = g.gpw >> 1; m >= 1; m >>= 1) need = max(need, __shfl_xor(need, m, 64));
-        if (!g.sync_stage) {   // ... asynchronous ring: over the block
-            for (int m = 32; m >= g.gpw; m >>= 1) need = max(need, __shfl_xor(need, m, 64));
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = need;
-            __syncthreads();
-            need = 0;
-            for (int v = 0; v < (int)(blockDim.x >> 6); ++v) need = max(need, red[v]);
-            __syncthreads();
-        }
-        const unsigned Te = g.sync_stage ? (unsigned)((need + 1) / 2)
-                                         : (unsigned)(((need + 1) / 2 + 3) / 4 * 4);   // plan.cpp::ring_schedule_block
+        const unsigned Te = (unsigned)((need + 1) / 2);   // plan.cpp::ring_schedule_block
         if (Te > 65535u) *err = 1;
-        if (g.sync_stage) {
-            if (owner && gi % g.gpw == 0) steps32[((size_t)b * g.wpb + gi / g.gpw) * g.W + e] = Te;
-        } else if (gi < g.wpb) {
-            steps32[((size_t)b * g.wpb + gi) * g.W + e] = Te;
-        }
+        if (owner && gi % g.gpw == 0) steps32[((size_t)b * g.wpb + gi / g.gpw) * g.W + e] = Te;
         if (owner) st[e] = done;
         done += min((int32_t)(2 * Te), (int32_t)(c_hor - r0) - done);
     }
@@ -335,7 +321,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         g.n_classes = shape.bank_order ? std::max(1, 16 / std::max(1, lpc)) : 1;
         g.row_slots = P.row_slots;
         g.ring = P.ring; g.slot16 = P.slot16; g.wpt = P.windows_per_task;
-        g.look = P.look; g.sync_stage = P.sync_stage;
+        g.look = P.look;
         const bool ring = P.ring > 1;
         const int64_t n_slots = P.n_blocks * P.gpb;
         Tmp d_rows((size_t)n_slots * 4);

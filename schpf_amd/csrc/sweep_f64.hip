@@ -5,9 +5,4 @@ template hipError_t launch_sweep<double>(const SweepArgs<double> &, int, int, in
 template hipError_t launch_random_phi<double>(const SweepArgs<double> &, int, int, uint64_t, int, int64_t, hipStream_t);
 template hipError_t launch_tile_sweep<double>(const TileArgs<double> &, int, int, int, int, int64_t, int, size_t, hipStream_t);
 template hipError_t launch_tile_sweep_dual<double>(const TileArgs<double> &, const TileArgs<double> &, const int *, int, int, int, int64_t, int, size_t, int *, int, hipStream_t);
-#ifdef SCHPF_WITH_RING
-bool ring_schedule_compiled() { return true; }
-#else
-bool ring_schedule_compiled() { return false; }
-#endif
 }  // namespace schpf

@@ -798,364 +798,10 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     store_lane<T, NV, LPC>(out_row, sub, acc);
 }
 
-// ----------------------------------------------------------- ring mode (plan.h)
-// ----------------------------------------------------------- ring schedule (plan.h), opt-in
-// Compiled only with -DSCHPF_WITH_RING (tools/devbuild.sh): it doubles the build time of this
-// file and is NOT the shipped schedule -- measured at BASELINE C3 it fills 0.80-0.85 of the step
-// slots against the window schedule's 0.68 and is still 8 % (f64) / 15 % (f32) slower, because a
-// workgroup-wide barrier every ~7 steps costs more SIMD occupancy around the barrier than the
-// padding it saves (profiles/r02/explore_ring_schedule.log).  Kept as the record of
-// that experiment and as the starting point for a barrier-free variant.
-#ifdef SCHPF_WITH_RING
-// One workgroup = one task, ring schedule (plan.h): the LDS is a ring of a.ring slots; epoch w (one
-// per sub-window of the task) runs the same number of steps in EVERY wave while sub-window
-// w + ring - 1 is copied into the slot of sub-window w - 1.  The step loop is the window schedule's;
-// what differs is the boundary: NO barrier -- two counters in LDS tell a wave when the rows it is
-// about to read have been stored and when the slot it is about to overwrite has been left by all
-// (a first version with a barrier per epoch lost more SIMD occupancy around its ~7-step barriers
-// than the schedule saves in padding) -- no exposed staging, and the entry prefetch ring runs on.
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
-__device__ __forceinline__ void tile_sweep_task_ring(const TileArgs<T> &a, const int task)
-{
-    typedef TileEntry<PACK> EF;
-    typedef typename EF::type E;
-    constexpr int VEC = Vec16<T>::N;
-    constexpr int KL = NV * VEC;
-    constexpr int GPW = 64 / LPC;
-    constexpr int KP = KL * LPC;
-    constexpr int RING = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-
-    const int blk = a.task_block[task], w0 = a.task_w0[task], w1 = a.task_w1[task];
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int grp = lane / LPC, sub = lane % LPC;
-    const int gpb = GPW * a.wpb;
-    const int g = wv * GPW + grp;
-    const int major = a.block_rows[(size_t)blk * gpb + g];
-    const bool live = major >= 0;
-
-    T tm[KL], acc[KL];
-#pragma unroll
-    for (int k = 0; k < KL; ++k) { tm[k] = T(0); acc[k] = T(0); }
-    if (MODE != MODE_RANDOM && live) load_lane<T, NV, LPC>(a.tab_major + (size_t)major * KP, sub, tm);
-    double llh = 0.0;
-    LlhAccumulator lacc;   // MODE_LLH
-    bool any_bad = false;
-    const T tiny = Vec16<T>::tiny();
-    // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
-    constexpr bool PAIR = KL * (int)sizeof(T) <= (MAXT <= 512 ? 192 : 96);
-    constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
-    T bA[KL], bB[KL];                                  // PIPE: the rows of the step being / about to be computed
-    float xc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};         //       counts of that step [step parity][nonzero]
-
-    // position (in step slots) of this group's entries; advances window by window
-    size_t pos = (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp;
-    const uint16_t *__restrict__ st = a.steps + ((size_t)blk * a.wpb + wv) * a.n_windows;
-
-    // steps of epoch e: every wave of the block has the same count; read through the scalar cache
-    // as an aligned 32-bit word (a 16-bit load would be a vector load and cost a vmcnt(0))
-    const uint32_t *__restrict__ st32 = reinterpret_cast<const uint32_t *>(a.steps);
-    const size_t st_base = ((size_t)blk * a.wpb + wv) * a.n_windows;
-    auto epoch_steps = [&](int e) {
-        const size_t h = st_base + (size_t)e;
-        return (int)((st32[h >> 1] >> (16 * (int)(h & 1))) & 0xFFFFu);
-    };
-    // Copy of sub-window sw into its ring slot: every wave moves 2 KiB (a.slot_bytes = 2 KiB x wpb), as
-    // two 16-byte loads per lane that sit in registers for a few steps and are then written to the
-    // LDS.  Plain loads and ds_write on purpose -- NOT the global_load_lds DMA of the window schedule:
-    // the compiler waits vmcnt(0) before any LDS read that follows a DMA it can see (it must assume
-    // they alias), and a DMA it cannot see (inline assembly) sits in the in-order vmcnt queue
-    // uncounted, which makes every counted wait of the entry prefetch ring stricter by the number of
-    // copies in flight (measured: one exposed HBM latency per epoch).  Loads the compiler can count
-    // cost 8 VGPRs for three steps and nothing else.
-    const int L = a.ring, slot_bytes = a.slot_bytes;
-    const unsigned char *__restrict__ tab_lane =
-        reinterpret_cast<const unsigned char *>(a.tab_minor) + (size_t)wv * 1024 + (size_t)lane * 16;
-    const size_t sub_bytes = (size_t)a.win_rows * KP * sizeof(T);
-    const int piece = a.wpb * 1024;                       // the wave's second 1 KiB lies one round of waves further
-    uint4 stg0 = make_uint4(0, 0, 0, 0), stg1 = make_uint4(0, 0, 0, 0);
-    auto stage_load = [&](int sw) {
-        const unsigned char *src = tab_lane + (size_t)sw * sub_bytes;
-        stg0 = *reinterpret_cast<const uint4 *>(src);
-        stg1 = *reinterpret_cast<const uint4 *>(src + piece);
-    };
-    // the last 64 bytes of every slot hold no table row (plan.cpp: rows per slot); slot 0's carry the
-    // two counters that order the waves of the workgroup WITHOUT a barrier per epoch
-    const bool tail_lane = piece + wv * 1024 + lane * 16 + 16 > slot_bytes - 64;   // only in the second piece
-    auto stage_store = [&](int sw) {
-        unsigned char *dst = lds_raw + (size_t)(sw % L) * slot_bytes + (size_t)wv * 1024 + (size_t)lane * 16;
-        *reinterpret_cast<uint4 *>(dst) = stg0;
-        if (!tail_lane) *reinterpret_cast<uint4 *>(dst + piece) = stg1;
-    };
-    // cnt[0] = (wave, epoch) completions, cnt[1] = (wave, copy) stores.  A wave that has finished
-    // epoch e adds 1 to cnt[0]; the slot of sub-window e may be overwritten once all wpb waves have
-    // (cnt[0] >= wpb * (e - w0 + 1)).  A wave that has stored its share of copy j (sub-window
-    // w0 + ring - 1 + j, made during epoch w0 + j) adds 1 to cnt[1]; the copy is readable once
-    // cnt[1] >= wpb * (j + 1).  LDS operations of one wave execute in issue order, so an add issued
-    // after the reads / writes it announces also happens after them.
-    unsigned *cnt = reinterpret_cast<unsigned *>(lds_raw + slot_bytes - 64);
-    auto counter = [&](int which) {
-        return (unsigned)__builtin_amdgcn_readfirstlane(
-            (int)__hip_atomic_load(cnt + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-    };
-    auto signal = [&](int which) {
-        if (lane == 0) __hip_atomic_fetch_add(cnt + which, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto wait_for = [&](int which, unsigned target) {
-        // bounded (about a second): a protocol error must show up as a wrong result in the tests, not
-        // as a hung GPU
-        for (int spin = 0; counter(which) < target && spin < (1 << 24); ++spin) __builtin_amdgcn_s_sleep(1);
-    };
-    const unsigned wpbu = (unsigned)a.wpb;
-    const int n_copies = max(0, (w1 - w0) - (L - 1));   // sub-windows beyond the ones staged up front
-
-    E ring[RING];
-    int steps = epoch_steps(w0);
-    // every ring load is unconditional (the entry buffer is padded, plan.cpp), so the number of
-    // loads in flight is a compile-time fact and the waits can be s_waitcnt vmcnt(RING - 1)
-#pragma unroll
-    for (int i = 0; i < RING; ++i) ring[i] = EF::load(a.entries, pos + (size_t)i * GPW);
-    if (MODE != MODE_RANDOM) {
-        const int first_end = min(w0 + L - 1, w1);
-        for (int sw = w0; sw < first_end; ++sw) { stage_load(sw); stage_store(sw); }   // readable in the first epoch
-        if (threadIdx.x == 0) { cnt[0] = 0u; cnt[1] = 0u; }
-        __syncthreads();                                   // the only barrier of the task
-    }
-
-    for (int w = w0; w < w1; ++w) {
-        const int steps_next = w + 1 < w1 ? epoch_steps(w + 1) : 0;   // scalar load, used at the boundary
-        // the sub-window copied during this epoch (into the slot retired at the last barrier); it
-        // becomes readable in the next epoch
-        const int stage_sw = (MODE != MODE_RANDOM && w + L - 1 < w1) ? w + L - 1 : -1;
-        const unsigned epoch_ix = (unsigned)(w - w0);
-        // this epoch reads up to sub-window w + ring - 2 = copy epoch_ix - 1: all shares stored?
-        if (MODE != MODE_RANDOM && epoch_ix >= 1u && n_copies > 0)
-            wait_for(1, wpbu * (unsigned)min((int)epoch_ix, n_copies));
-        bool stored = stage_sw < 0;
-        // the copy of this epoch goes into the slot of sub-window w - 1: free once every wave has
-        // finished epoch w - 1.  Tried once, with the last step of the first round (the pieces are in
-        // registers then); a wave that is more than a round ahead of the slowest one stores at the end
-        // of the epoch instead, after loading the pieces again.
-        auto try_store = [&]() {
-            if (!stored && counter(0) >= wpbu * epoch_ix) { stage_store(stage_sw); signal(1); stored = true; }
-        };
-        if (PIPE) {
-            // Rolling LDS pipeline, one nonzero deep: the minor rows of step p+1 are fetched from the
-            // window while step p is still being computed -- row A' right after nonzero A has been
-            // consumed, into the same registers, then the same for B.  A wave never starts a step
-            // by waiting a full LDS latency (measured: the unpipelined loop overlapped the LDS read
-            // phase and the FMA phase of the 4 waves of a SIMD poorly).
-            if (steps > 0) {   // prologue: the first step's rows (the ring was primed before the barrier)
-                const E c = ring[0];
-                unsigned i0 = EF::idx(c, 0), i1 = EF::idx(c, 1);
-                xc[0][0] = EF::val(c, 0); xc[0][1] = EF::val(c, 1);
-                asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xc[0][0]), "+v"(xc[0][1]));
-                load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i0), sub, bA);
-                load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i1), sub, bB);
-            }
-            // One round of RING steps.  The FIRST round of an epoch also carries the copy of the next
-            // sub-window: its loads are issued unconditionally with the first step and stored with the
-            // last, in a body of its own, so that the compiler's counted vmcnt waits stay exact in both
-            // bodies (a load under a condition makes every later wait assume the stricter case, which
-            // forces entry loads issued one step ago to complete: an HBM latency per epoch).
-            auto round = [&](auto first_tag, const int p) {
-                constexpr bool FIRST = decltype(first_tag)::value;
-#pragma unroll
-                for (int i = 0; i < RING; ++i) {
-                    // slot i was decoded one step ago: refill it; decode the NEXT step's slot.  Past the
-                    // epoch's last step that is the next epoch's entry: its rows are loaded again after
-                    // the barrier
-                    ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
-                    if (FIRST && i == 0) stage_load(stage_sw >= 0 ? stage_sw : w);   // always issued
-                    if (p + i < steps) {                               // scalar branch
-                        const E cn = ring[(i + 1) % RING];
-                        unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
-                        // counts alternate between two register pairs (RING is even), no copies
-                        xc[(i + 1) & 1][0] = EF::val(cn, 0); xc[(i + 1) & 1][1] = EF::val(cn, 1);
-                        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(xc[(i + 1) & 1][0]), "+v"(xc[(i + 1) & 1][1]));
-                        const T x0 = (T)xc[i & 1][0], x1 = (T)xc[i & 1][1];
-                        const T s0 = group_dot<T, KL, LPC>(tm, bA);
-                        if (MODE == MODE_PHI) {
-                            // no test of the normaliser here: a product-form s that underflowed (zero /
-                            // denormal) makes the reciprocal inf, and inf * b or 0 * inf poisons EVERY
-                            // accumulator of every lane of the group (inf or NaN) -- detected once, after
-                            // the task, and the group is then redone by the cold path.  A small but
-                            // normal s is exact enough: its largest term is a normal number.
-                            const T q0 = fast_div(x0, s0);
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
-                        }
-                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
-                        // nothing moves across: row A' must be requested BEFORE nonzero B is computed
-                        __builtin_amdgcn_sched_barrier(0);
-                        const T s1 = group_dot<T, KL, LPC>(tm, bB);
-                        if (MODE == MODE_PHI) {
-                            const T q1 = fast_div(x1, s1);
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
-                        }
-                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
-                        if (MODE == MODE_LLH) {
-                            if (LPC == 1) {
-                                if (x0 > T(0)) lacc.add((double)x0, (double)s0);
-                                if (x1 > T(0)) lacc.add((double)x1, (double)s1);
-                            } else {
-                                // every lane of the group knows s0 and s1: lane 0 takes the first
-                                // nonzero, lane 1 the second
-                                const T sm = (sub & 1) ? s1 : s0;
-                                const T xm = (sub & 1) ? x1 : x0;
-                                if (sub < 2 && xm > T(0)) lacc.add((double)xm, (double)sm);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (FIRST && i == RING - 1) try_store();
-                }
-            };
-            if (steps > 0) {
-                round(std::true_type{}, 0);
-                for (int p = RING; p < steps; p += RING) round(std::false_type{}, p);
-            }
-        } else
-        for (int p = 0; p < steps; p += RING) {
-#pragma unroll
-            for (int i = 0; i < RING; ++i) {
-                const E c = ring[i];
-                unsigned i0 = EF::idx(c, 0), i1 = EF::idx(c, 1);
-                float xf0 = EF::val(c, 0), xf1 = EF::val(c, 1);
-                // decode before the refill so that the slot's registers are free for it (otherwise
-                // the refill lands in other registers and the loop needs copies behind a vmcnt(0))
-                asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xf0), "+v"(xf1));
-                ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);   // may run past: padded
-                if (i == 0 && p == 0 && stage_sw >= 0) stage_load(stage_sw);
-                if (p + i < steps) {                                   // scalar branch
-                    if (MODE == MODE_RANDOM) {
-                        // t = 0 responsibilities (reference scHPF_.py:652-655), counter-based draws
-#pragma unroll 1
-                        for (int u = 0; u < 2; ++u) {
-                            const unsigned minor = (unsigned)entry_minor(u ? i1 : i0, w, a.win_rows, KP * (int)sizeof(T) / 16, L, slot_bytes >> 4);
-                            const double x = (double)(u ? xf1 : xf0);
-                            if (!(x > 0.0)) continue;
-                            const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
-                            const uint64_t gene = a.major_is_cell ? (uint64_t)minor : (uint64_t)major;
-                            const uint64_t base = draw_base(a.seed, cell, gene);
-                            double d[KL];
-                            double s = 0.0;
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) {
-                                const int f = factor_of<T, LPC>(k, sub);
-                                d[k] = f < a.K ? exp1_draw(base, (unsigned)f) : 0.0;
-                                s += d[k];
-                            }
-                            s = group_sum<double, LPC>(s);
-                            const double wgt = x / s;
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] += (T)(wgt * d[k]);
-                        }
-                    } else {
-                        // narrow rows: both nonzeros of the step in flight; wide rows: one at a time
-                        if (PAIR) {
-                            T b0[KL], b1[KL];
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i0), sub, b0);
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i1), sub, b1);
-                            const T x0 = (T)xf0, x1 = (T)xf1;
-                            const T s0 = group_dot<T, KL, LPC>(tm, b0);
-                            const T s1 = group_dot<T, KL, LPC>(tm, b1);
-                            if (MODE == MODE_PHI) {
-                                const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;
-                                const T q0 = safe_weight(x0, s0, ok0), q1 = safe_weight(x1, s1, ok1);
-                                any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
-#pragma unroll
-                                for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, b1[k], fma_t(q0, b0[k], acc[k]));
-                            } else if (LPC == 1) {
-                                if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
-                                if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
-                            } else {
-                                // every lane of the group knows s0 and s1: lane 0 takes the log of the
-                                // first nonzero, lane 1 of the second (the f64 log is the costly part)
-                                const T sm = (sub & 1) ? s1 : s0;
-                                const T xm = (sub & 1) ? x1 : x0;
-                                if (sub < 2 && xm > T(0)) llh += (double)xm * log((double)sm) - (double)sm;
-                            }
-                        } else {
-#pragma unroll 1
-                            for (int u = 0; u < 2; ++u) {
-                                T b[KL];
-                                load_lane<T, NV, LPC>(lds_row<T>(lds_raw, u ? i1 : i0), sub, b);
-                                const T x = (T)(u ? xf1 : xf0);
-                                const T s = group_dot<T, KL, LPC>(tm, b);
-                                if (MODE == MODE_PHI) {
-                                    const bool ok = s >= tiny;
-                                    const T q = safe_weight(x, s, ok);
-                                    any_bad |= x > T(0) && !ok;
-#pragma unroll
-                                    for (int k = 0; k < KL; ++k) acc[k] = fma_t(q, b[k], acc[k]);
-                                } else {
-                                    // wide rows: lane 0 of the group keeps the group's share
-                                    if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
-                                }
-                            }
-                        }
-                    }
-                    // keep the steps apart: without this fence the compiler hoists every LDS row
-                    // load of the unrolled ring to the top and spills
-                    asm volatile("" ::: "memory");
-                }
-                if (i == RING - 1 && p == 0) try_store();
-            }
-        }
-        // an epoch's entries are stored padded to a multiple of RING steps (plan.cpp), so the ring
-        // already holds the first steps of the next epoch in the right slots: no re-priming
-        pos += (size_t)((steps + RING - 1) / RING * RING) * GPW;
-        if (MODE != MODE_RANDOM && w + 1 < w1) {
-            if (!stored) {                                  // empty epoch, or this wave ran ahead
-                wait_for(0, wpbu * epoch_ix);
-                stage_load(stage_sw);
-                stage_store(stage_sw);
-                signal(1);
-            }
-            signal(0);                                      // every LDS read of this epoch has been issued
-        }
-        if (w + 1 < w1) steps = steps_next;
-    }
-
-    if (MODE == MODE_LLH) {
-        llh += lacc.total();   // zero where nothing was added
-        // which lanes hold a share: all (LPC 1), lanes 0-1 of a group (paired steps), lane 0 (else)
-        if (LPC > 1 && !(PAIR ? sub < 2 : sub == 0)) llh = 0.0;
-        llh = wave_sum(llh);
-        if (lane == 0) a.wave_out[(size_t)task * a.wpb + wv] = llh;
-        return;
-    }
-    T *out_row = a.partials + ((size_t)task * gpb + g) * KP;
-    if (MODE == MODE_PHI && PIPE) {   // non-finite accumulators <=> some normaliser underflowed (see the loop)
-        T probe = T(0);
-#pragma unroll
-        for (int k = 0; k < KL; ++k) probe = fma_t(acc[k], T(0), probe);   // 0, or NaN
-        any_bad = !(probe == T(0));
-    }
-    if (MODE == MODE_PHI && __builtin_expect(any_bad && live, 0)) {   // group-uniform; rare: see slow_nonzero
-        slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
-                                        a.win_rows, L, slot_bytes >> 4, GPW, a.log_major + (size_t)major * KP, a.log_minor, sub,
-                                        a.K, out_row);
-        return;
-    }
-    if (MODE == MODE_PHI) {
-#pragma unroll
-        for (int k = 0; k < KL; ++k) acc[k] = live ? acc[k] * tm[k] : T(0);
-    }
-    // dead groups write zeros too: every partial row of the task is defined after a sweep
-    store_lane<T, NV, LPC>(out_row, sub, acc);
-}
-
-#endif  // SCHPF_WITH_RING
 
 template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
-#ifdef SCHPF_WITH_RING
-    if (a.ring > 1 && !a.sync_stage) { tile_sweep_task_ring<T, NV, LPC, MODE, MAXT, PACK>(a, task); return; }
-#endif
     tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK>(a, task);
 }
 
@@ -1251,8 +897,8 @@ static hipError_t launch_tile_b(const TileArgs<T> &a_in, int mode, int64_t n_tas
         hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>), grid, block, lds_bytes, st, a);
     else if (mode == MODE_LLH)
         hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>), grid, block, lds_bytes, st, a);
-    else
-        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_RANDOM, MAXT, PACK>), grid, block, 0, st, a);
+    else   // one-off: the 1024-thread bound serves every workgroup size (one instantiation instead of two)
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_RANDOM, 1024, PACK>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 // the launch bound caps the register budget: 1024 threads -> 128 VGPRs, 512 -> 256
@@ -1322,53 +968,36 @@ static hipError_t launch_random_t(const SweepArgs<T> &a, uint64_t seed, int majo
     return hipGetLastError();
 }
 
-#define SCHPF_FOR_LPC(LPC_VAR, CALL)                                          \
-    switch (LPC_VAR) {                                                        \
-    case 1: { constexpr int LPC = 1; return CALL; }                           \
-    case 2: { constexpr int LPC = 2; return CALL; }                           \
-    case 4: { constexpr int LPC = 4; return CALL; }                           \
-    case 8: { constexpr int LPC = 8; return CALL; }                           \
-    case 16: { constexpr int LPC = 16; return CALL; }                         \
-    default: return hipErrorInvalidValue;                                     \
-    }
-#ifdef SCHPF_DEV_FAST   /* development builds: only the K = 20 instantiations (tools/devbuild.sh) */
+// Only the (vectors per lane, lanes per row) pairs that capi.hip choose_config can pick are instantiated
+// (kernels.h tile_combo_ok / gather_combo_ok list them): every pair costs 16 tile kernels or 3 gather
+// kernels per dtype, and the full 9 x 5 grid made a 21 MB library.
+#define SCHPF_COMBO(nv_, lpc_, CALLEXPR)                                      \
+    if (nv == nv_ && lpc == lpc_) { constexpr int NV = nv_; constexpr int LPC = lpc_; return CALLEXPR; }
+#ifdef SCHPF_DEV_FAST   /* development builds: only the K = 20 and K = 50 instantiations (tools/devbuild.sh) */
+#define SCHPF_DISPATCH_TILE(nv, lpc, CALLEXPR)                                \
+    SCHPF_COMBO(5, 1, CALLEXPR) SCHPF_COMBO(5, 2, CALLEXPR) SCHPF_COMBO(7, 4, CALLEXPR) SCHPF_COMBO(7, 2, CALLEXPR) \
+    return hipErrorInvalidValue;
 #define SCHPF_DISPATCH(nv, lpc, CALLEXPR)                                     \
-    if (nv == 5 && lpc == 1) { constexpr int NV = 5; constexpr int LPC = 1; return CALLEXPR; } \
-    if (nv == 5 && lpc == 2) { constexpr int NV = 5; constexpr int LPC = 2; return CALLEXPR; } \
-    if (nv == 7 && lpc == 4) { constexpr int NV = 7; constexpr int LPC = 4; return CALLEXPR; } /* K = 50 */ \
-    if (nv == 7 && lpc == 2) { constexpr int NV = 7; constexpr int LPC = 2; return CALLEXPR; } \
+    SCHPF_COMBO(5, 4, CALLEXPR) SCHPF_COMBO(3, 4, CALLEXPR) SCHPF_COMBO(7, 4, CALLEXPR) SCHPF_COMBO(4, 4, CALLEXPR) \
     return hipErrorInvalidValue;
 #else
-#define SCHPF_DISPATCH(nv, lpc, CALLEXPR)                                     \
-    switch (nv) {                                                             \
-    case 1: { constexpr int NV = 1; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 2: { constexpr int NV = 2; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 3: { constexpr int NV = 3; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 4: { constexpr int NV = 4; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 5: { constexpr int NV = 5; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 6: { constexpr int NV = 6; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 7: { constexpr int NV = 7; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 8: { constexpr int NV = 8; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 10: { constexpr int NV = 10; SCHPF_FOR_LPC(lpc, CALLEXPR) }          \
-    default: return hipErrorInvalidValue;                                     \
-    }
-#endif
-// the tile sweeps never see more than 7 vectors per lane (capi.hip choose_config: at most 112 row
-// bytes per lane); not instantiating 8 and 10 for them saves a fifth of this file's build time
-#ifdef SCHPF_DEV_FAST
-#define SCHPF_DISPATCH_TILE(nv, lpc, CALLEXPR) SCHPF_DISPATCH(nv, lpc, CALLEXPR)
-#else
+// tile sweeps: LPC 1 with 1..7 vectors; LPC 2, 4, 8 with 4..7; LPC 16 with 4 (rows of at most 1 KiB)
 #define SCHPF_DISPATCH_TILE(nv, lpc, CALLEXPR)                                \
-    switch (nv) {                                                             \
-    case 1: { constexpr int NV = 1; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 2: { constexpr int NV = 2; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 3: { constexpr int NV = 3; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 4: { constexpr int NV = 4; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 5: { constexpr int NV = 5; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 6: { constexpr int NV = 6; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    case 7: { constexpr int NV = 7; SCHPF_FOR_LPC(lpc, CALLEXPR) }            \
-    default: return hipErrorInvalidValue;                                     \
-    }
+    SCHPF_COMBO(1, 1, CALLEXPR) SCHPF_COMBO(2, 1, CALLEXPR) SCHPF_COMBO(3, 1, CALLEXPR) SCHPF_COMBO(4, 1, CALLEXPR) \
+    SCHPF_COMBO(5, 1, CALLEXPR) SCHPF_COMBO(6, 1, CALLEXPR) SCHPF_COMBO(7, 1, CALLEXPR)                             \
+    SCHPF_COMBO(4, 2, CALLEXPR) SCHPF_COMBO(5, 2, CALLEXPR) SCHPF_COMBO(6, 2, CALLEXPR) SCHPF_COMBO(7, 2, CALLEXPR) \
+    SCHPF_COMBO(4, 4, CALLEXPR) SCHPF_COMBO(5, 4, CALLEXPR) SCHPF_COMBO(6, 4, CALLEXPR) SCHPF_COMBO(7, 4, CALLEXPR) \
+    SCHPF_COMBO(4, 8, CALLEXPR) SCHPF_COMBO(5, 8, CALLEXPR) SCHPF_COMBO(6, 8, CALLEXPR) SCHPF_COMBO(7, 8, CALLEXPR) \
+    SCHPF_COMBO(4, 16, CALLEXPR)                                              \
+    return hipErrorInvalidValue;
+// gather sweeps: LPC 4 with 1..8, 10 vectors; LPC 8 with 6, 7, 8, 10; LPC 16 with 6, 7, 8
+#define SCHPF_DISPATCH(nv, lpc, CALLEXPR)                                     \
+    SCHPF_COMBO(1, 4, CALLEXPR) SCHPF_COMBO(2, 4, CALLEXPR) SCHPF_COMBO(3, 4, CALLEXPR) SCHPF_COMBO(4, 4, CALLEXPR) \
+    SCHPF_COMBO(5, 4, CALLEXPR) SCHPF_COMBO(6, 4, CALLEXPR) SCHPF_COMBO(7, 4, CALLEXPR) SCHPF_COMBO(8, 4, CALLEXPR) \
+    SCHPF_COMBO(10, 4, CALLEXPR)                                              \
+    SCHPF_COMBO(6, 8, CALLEXPR) SCHPF_COMBO(7, 8, CALLEXPR) SCHPF_COMBO(8, 8, CALLEXPR) SCHPF_COMBO(10, 8, CALLEXPR) \
+    SCHPF_COMBO(6, 16, CALLEXPR) SCHPF_COMBO(7, 16, CALLEXPR) SCHPF_COMBO(8, 16, CALLEXPR)                          \
+    return hipErrorInvalidValue;
 #endif
 
 template <typename T>

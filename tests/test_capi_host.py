@@ -118,14 +118,12 @@ def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_
     return om, on, ov, oprow, otask, pfirst, pcount, [int(s) for s in stats]
 
 
-# (lpc, waves per block, rows per window, target tasks, ring slots, bytes per slot): ring 1 = window
-# schedule; ring >= 3 = ring schedule, whose rows per sub-window follow from the slot (160-byte rows);
-# ring <= -2 = half-window schedule with -ring slots
+# (lpc, waves per block, rows per window, target tasks, slots, bytes per slot): 1 = window schedule;
+# <= -2 = half-window schedule with that many slots, whose rows per sub-window follow from the slot
+# (160-byte rows)
 @pytest.mark.parametrize("lpc,wpb,win_rows,tasks,ring,slot_bytes",
                          [(4, 8, 64, 64, 1, 0), (2, 4, 37, 1, 1, 0), (1, 1, 1000, 7, 1, 0), (8, 2, 5, 1000, 1, 0),
                           (16, 8, 300, 16, 1, 0),
-                          (2, 4, 0, 16, 5, 8192), (1, 1, 0, 1, 3, 1024), (4, 8, 0, 64, 4, 16384), (2, 16, 0, 1000, 5, 32768),
-                          (1, 2, 0, 7, 8, 2048),
                           (2, 4, 0, 16, -2, 8192), (1, 1, 0, 1, -2, 1024), (2, 16, 0, 1000, -2, 77824), (4, 8, 0, 64, -3, 4000)])
 @pytest.mark.parametrize("coo_order", ["shuffled", "row-major", "col-major"])
 def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_order):

@@ -17,26 +17,22 @@ from conftest import load_golden, golden_coo, synthetic_counts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["tile", "half", "ring", "gather"])
+@pytest.fixture(autouse=True, params=["tile", "half", "gather"])
 def plan_kind(request, monkeypatch):
-    """Every engine test runs on all sweep implementations: the LDS-staged tile plan with the window
-    schedule ("tile", what ships), with the half-window schedule ("half": SCHPF_HALF=2), with the
-    experimental ring schedule when the library was built
-    with it ("ring": SCHPF_RING=4), and the L2-gather plan (selected by the library from
-    SCHPF_PLAN at upload time)."""
-    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param in ("ring", "half") else request.param)
+    """Every engine test runs on all sweep implementations: the LDS-staged tile plan with the
+    schedule the library picks ("tile", what ships), with the half-window schedule forced ("half":
+    SCHPF_HALF=2), and the L2-gather plan (selected by the library from SCHPF_PLAN at upload time).
+    A test that belongs to some of them narrows the list with `only_plans(...)` -- no ids that can
+    only skip."""
+    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param == "half" else request.param)
     monkeypatch.delenv("SCHPF_HALF", raising=False)
     if request.param == "half":
         monkeypatch.setenv("SCHPF_HALF", "2")
-    if request.param == "ring":
-        from schpf_amd import _lib
-        if b"+ring" not in _lib.load().schpf_version():
-            pytest.skip("the ring schedule is an opt-in experiment, not compiled into the shipped library "
-                        "(DEVFLAGS=-DSCHPF_WITH_RING tools/devbuild.sh)")
-        monkeypatch.setenv("SCHPF_RING", "4")
-    else:
-        monkeypatch.delenv("SCHPF_RING", raising=False)
     return request.param
+
+
+def only_plans(*kinds):
+    return pytest.mark.parametrize("plan_kind", list(kinds), indirect=True)
 
 
 @pytest.fixture(scope="module")
@@ -336,12 +332,11 @@ def test_mass_conservation_at_benchmark_shape(amd, oracle):
         assert np.all(np.isfinite(ths)) and np.all(thr > 0) and np.all(ber > 0)
 
 
+@only_plans("tile")
 def test_mass_conservation_at_headline_shape(amd, oracle, plan_kind):
     """The same size-independent properties at the headline shape (BASELINE C3: 100k x 20k, K=20,
     1024-thread workgroups, 152 KiB windows, the dual launch) with 1 % of the entries filled, in
     float64: row / column sums, agreeing k-marginals, the loss against the oracle."""
-    if plan_kind != "tile":
-        pytest.skip("one plan kind is enough at this size")
     X = synthetic_counts(100000, 20000, 0.01, seed=42)
     K, a, c = 20, 0.3, 0.3
     bp, dp, st = random_state(oracle, X, K, np.float64, seed=0)
@@ -360,11 +355,10 @@ def test_mass_conservation_at_headline_shape(amd, oracle, plan_kind):
     assert_allclose(loss, want, rtol=1e-11)
 
 
+@only_plans("tile", "half")
 def test_xcd_launch_order_changes_nothing_but_the_order(amd, oracle, plan_kind, monkeypatch):
     """SCHPF_XCD=8 (plan.h xcd_launch_order: same-range tasks share an XCD) permutes the launch slots of
     the merged sweep; every task still runs exactly once, so the iteration is bitwise the same."""
-    if plan_kind not in ("tile", "half"):
-        pytest.skip("the merged launch order belongs to the tile plan")
     X = synthetic_counts(3000, 2500, 0.05, seed=11)
     K, a, c = 20, 0.3, 0.3
     bp, dp, st = random_state(oracle, X, K, np.float64, seed=3)
@@ -381,12 +375,11 @@ def test_xcd_launch_order_changes_nothing_but_the_order(amd, oracle, plan_kind, 
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
+@only_plans("tile", "half")
 def test_persistent_dual_launch_equals_one_workgroup_per_task_bitwise(amd, oracle, plan_kind, monkeypatch):
     """The dual sweep launch as persistent workgroups that draw tasks from a device counter (default)
     against one workgroup per task (SCHPF_PERSISTENT=0), with more tasks than the device holds at once so
     that the counter is actually used, over several launches (the counter re-arms itself): bitwise equal."""
-    if plan_kind not in ("tile", "half"):
-        pytest.skip("the dual launch belongs to the tile plan")
     X = synthetic_counts(20000, 8000, 0.015, seed=12)        # 40 blocks x 9 windows + 16 x 21: > 256 tasks
     K, a, c = 20, 0.3, 0.3
     bp, dp, st = random_state(oracle, X, K, np.float64, seed=4)
@@ -530,6 +523,7 @@ BENCH_SHAPES = [   # the workloads bench.py times (BASELINE.json configs[2] and 
 ]
 
 
+@only_plans("tile")
 @pytest.mark.parametrize("N,G,dens,K,dtype", BENCH_SHAPES)
 def test_benchmarked_workloads_match_oracle_on_sampled_rows(amd, oracle, plan_kind, N, G, dens, K, dtype):
     """Parity AT the sizes bench.py reports: BASELINE C3 as stated (100k x 20k, 5 %, K=20) and
@@ -538,9 +532,6 @@ def test_benchmarked_workloads_match_oracle_on_sampled_rows(amd, oracle, plan_ki
     genes (every updated quantity of those rows, small-case tolerances), (ii) by the
     size-independent conservation laws over ALL rows, (iii) the loss against the oracle's
     threaded compute_pois_llh over all nonzeros."""
-    if plan_kind != "tile":
-        pytest.skip("'tile' lets the library choose the schedule, as bench.py does (the ring schedule at C3, "
-                    "the window schedule at the C5 share); forced variants are covered by the small cases")
     X = _bench_matrix(N, G, dens)
     a, c = 0.3, 0.3
     bp, dp, st = random_state(oracle, X, K, dtype, seed=0)
@@ -767,13 +758,12 @@ def test_skewed_expression_matrix_matches_oracle(amd, oracle):
             assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-10)
 
 
+@only_plans("tile", "half")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, monkeypatch):
     """One launch for both orientations (tile_sweep_dual_kernel) runs the same tasks with the same
     fixed-order reductions as one launch per orientation: identical bits, and run-to-run
     deterministic (no atomics anywhere)."""
-    if plan_kind == "gather":
-        pytest.skip("the gather plan has no dual launch")
     X = synthetic_counts(3000, 2500, 0.04, seed=5)
     K = 20
     bp, dp, st = random_state(oracle, X, K, dtype, seed=2)
@@ -789,6 +779,7 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
             assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
 
 
+@only_plans("tile", "half")
 @pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
 @pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True)])
 def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_order, dtype, K, big):
@@ -796,8 +787,6 @@ def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_o
     fill) is the host builder's plan bit for bit: same entry order => same summation order => the
     engines agree in every bit after three iterations, from a host-drawn t=0 included (that path
     uses the plan's sort permutation)."""
-    if plan_kind == "gather":
-        pytest.skip("the gather plan is always built on the host")
     from scipy.sparse import coo_matrix
     # col-major input also gets long segments (40 % filled: > 192 nonzeros per row and window)
     X = synthetic_counts(600, 2600, 0.4, seed=11) if coo_order == "col-major" else synthetic_counts(2500, 1800, 0.05, seed=11)

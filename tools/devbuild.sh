@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development build: only the K = 20 sweep instantiations (seconds instead of minutes per file).
 #   tools/devbuild.sh            -> schpf_amd/libschpf_hip_dev.so  (use with SCHPF_LIB_PATH=...)
-#   DEVFLAGS=-DSCHPF_WITH_RING tools/devbuild.sh   also compiles the opt-in ring schedule (SCHPF_RING=4)
+
 set -e
 cd "$(dirname "$0")/../schpf_amd/csrc"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function"
