@@ -56,6 +56,52 @@ def synthetic_block(ncells, ngenes, density, seed):
     return X
 
 
+def synthetic_slabs(ncells, ngenes, density, seed, slab_rows=25000, threads=None):
+    """Generator A for matrices of several 1e8 draws (all of C5: 5e8): the same recipe drawn slab by
+    slab of `slab_rows` cells, one RandomState(seed + slab) and one thread per slab (NumPy releases the
+    GIL in the draws and in sort), duplicates summed by sorting packed (row, col, count) keys and
+    adding up runs -- coo_matrix.sum_duplicates lexsorts 5e8 entries on one core for minutes.  The
+    result is canonical (row-major, unique) and does not depend on the number of threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    bits = max(1, int(ngenes - 1).bit_length())
+    starts = list(range(0, ncells, slab_rows))
+
+    def draw(i):
+        r0 = starts[i]
+        nr = min(slab_rows, ncells - r0)
+        rng = np.random.RandomState(seed + i)
+        n = int(round(nr * ngenes * density))
+        x = rng.negative_binomial(2, 0.5, n)
+        x[x == 0] = 1
+        np.minimum(x, 255, out=x)                      # P(count > 255) is 2^-250; keeps the count in 8 key bits
+        key = rng.randint(0, nr, n).astype(np.int64)
+        key <<= bits
+        key |= rng.randint(0, ngenes, n)
+        key <<= 8
+        key |= x
+        del x
+        key.sort()
+        pos = key >> 8
+        first = np.empty(n, dtype=bool)
+        first[:1] = True
+        np.not_equal(pos[1:], pos[:-1], out=first[1:])
+        idx = np.flatnonzero(first)
+        counts = np.add.reduceat(key & 255, idx).astype(np.int32)
+        pos = pos[idx]
+        return (pos >> bits).astype(np.int32) + np.int32(r0), (pos & ((1 << bits) - 1)).astype(np.int32), counts
+
+    workers = threads or max(1, min(len(starts), len(os.sched_getaffinity(0)), 32))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        parts = list(pool.map(draw, range(len(starts))))
+    row = np.concatenate([p[0] for p in parts])
+    col = np.concatenate([p[1] for p in parts])
+    val = np.concatenate([p[2] for p in parts])
+    del parts
+    X = coo_matrix((val, (row, col)), shape=(ncells, ngenes), dtype=np.int32)
+    X.has_canonical_format = True
+    return X
+
+
 def planted_block(ncells, ngenes, K, target_events, seed):
     """Generator B of SURVEY.md 8(d): counts from a planted Gamma-Poisson factor model, so that
     the reference's stop rule has something to converge to.  x_ig ~ Poisson(sum_k theta_ik
@@ -179,6 +225,56 @@ def _time_iterations(fn, budget_s, max_iters):
     return (time.perf_counter() - t0) / iters, iters
 
 
+def host_cpus():
+    """What this process can actually run on: logical CPUs, the affinity mask, and the cgroup CPU quota
+    (cgroup v2 cpu.max / v1 cfs_quota).  A box may show 256 logical CPUs to a container that is allowed
+    16 CPU-seconds per second: threads beyond the quota only add throttling."""
+    import math
+    info = {"logical": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)), "cgroup_cpu_max": None}
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            info["cgroup_cpu_max"] = float(quota) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+            if q > 0:
+                info["cgroup_cpu_max"] = q / per
+        except (OSError, ValueError):
+            pass
+    usable = info["affinity"]
+    if info["cgroup_cpu_max"]:
+        usable = max(1, min(usable, int(math.ceil(info["cgroup_cpu_max"]))))
+    info["usable"] = usable
+    return info
+
+
+def _mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return float(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def _team_sizes(host):
+    """Candidate thread counts, largest first: the usable cores and its halvings down to 4, plus twice
+    the usable cores when the affinity mask allows (SMT siblings) -- never the raw logical count of a
+    quota-limited container."""
+    sizes, n = [], host["usable"]
+    if 2 * n <= host["affinity"]:
+        sizes.append(2 * n)
+    while n >= 4:
+        sizes.append(n)
+        n //= 2
+    return sizes or [max(1, host["usable"])]
+
+
 def cpu_baseline(X, K, dtype):
     """Both CPU comparators of SURVEY.md 8(d), timed on this box's host cores.
 
@@ -186,71 +282,106 @@ def cpu_baseline(X, K, dtype):
          thread-parallel Xphi (nnz x K materialised, K exp per nonzero) and llh, SERIAL
          scatter-adds and rate updates (hpf_numba.py:24,54 parallel; :128,159 serial).  This is
          the stand-in for "the reference numba CPU path" (numba itself is not installable here) and
-         is what `value` reports.  It needs 16 GB and minutes per iteration at C3, so it is timed
-         on TWO bounded row-subsamples (about 1/8 and 1/4 of the nonzeros); time is fitted as
-         alpha * nnz + gamma and extrapolated to the whole matrix; the two plain nnz-scalings are
-         reported beside it as the spread.
+         is what `value` reports.  Its team size is chosen by measurement on a 1/16 row sample
+         (like (ii)'s), then the WHOLE matrix is iterated when the host has the memory for the
+         materialised Xphi (nnz * K * itemsize, 16 GB at C3 f64, + the matrix): one untimed
+         iteration, then timed ones.  Only a host without that memory gets the two-point
+         extrapolation from 1/8 and 1/4 of the cells (and the line says so).
     (ii) "fused OpenMP" (oracle/cavi_fused_impl.h): exp hoisted, no Xphi, parallel CSR + CSC
          passes, AVX2 -- the best CPU form this build knows, on the WHOLE matrix, so that the
-         GPU/CPU ratio is not flattered by the reference's serial scatter."""
+         GPU/CPU ratio is not flattered by the reference's serial scatter.
+
+    `cores` is the number of threads the reported figure actually ran with; `host` says what the
+    box offers (logical CPUs, affinity, cgroup quota)."""
     from oracle import hpf_oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    host = host_cpus()
     N, G = X.shape
     nnz_full = X.nnz
-    points = []
-    for frac_target in (2.5e8, 5.0e8):             # nnz*K element budget of a sample (1/8 and 1/4 of C3)
-        target_nnz = min(nnz_full, int(frac_target / K))
+    itemsize = np.dtype(dtype).itemsize
+
+    def sample(target_elems):
+        target_nnz = min(nnz_full, int(target_elems / K))
         rows = max(1, int(N * target_nnz / max(nnz_full, 1)))
         keep = X.row < rows
-        Xs = coo_matrix((X.data[keep], (X.row[keep], X.col[keep])), shape=(rows, G))
-        bp, dp, st = _oracle_state(orc, Xs, K, dtype)
-        x, row, col = Xs.data, Xs.row, Xs.col
-        dt, iters = _time_iterations(
-            lambda: orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=cores), 6.0, 3)
-        points.append({"cells": rows, "nnz": int(Xs.nnz), "s_per_iter": dt, "iterations": iters,
-                       "scaled_by_nnz_it_per_s": (1.0 / dt) * Xs.nnz / float(nnz_full)})
-        if Xs.nnz == nnz_full:
-            break
-    if len(points) == 2 and points[1]["nnz"] > points[0]["nnz"]:
-        alpha = (points[1]["s_per_iter"] - points[0]["s_per_iter"]) / float(points[1]["nnz"] - points[0]["nnz"])
-        gamma = points[1]["s_per_iter"] - alpha * points[1]["nnz"]
-        if alpha <= 0:                              # timing noise: fall back to plain scaling
-            alpha, gamma = points[1]["s_per_iter"] / points[1]["nnz"], 0.0
-        full_s = alpha * nnz_full + max(gamma, 0.0)
-    else:
-        full_s = points[-1]["s_per_iter"] * nnz_full / float(points[-1]["nnz"])
-    value = 1.0 / full_s
-    scaled = [p["scaled_by_nnz_it_per_s"] for p in points]
-    spread = (max(scaled + [value]) - min(scaled + [value])) / value
+        return coo_matrix((X.data[keep], (X.row[keep], X.col[keep])), shape=(rows, G)), rows
 
-    # (ii) fused OpenMP on the whole matrix.  Its thread count is chosen by measurement: on a
-    # many-core host all hardware threads are not the fastest (the passes are gathers bound by the
-    # memory system; 256 threads measured 2.4x slower than 8 on one box), so one iteration is tried
-    # at cores, cores/2, ... and the best count is timed and reported
+    # team size of (i), by measurement on ~1/16 of C3 (nnz * K = 1.25e8 elements)
+    Xs, _ = sample(1.25e8)
+    bp, dp, st = _oracle_state(orc, Xs, K, dtype)
+    trial_i = {}
+    for n in _team_sizes(host):
+        orc.cavi_iteration(Xs.data, Xs.row, Xs.col, st, 0.3, 0.3, bp, dp, nthreads=n)      # warm-up of this team
+        t0 = time.perf_counter()
+        orc.cavi_iteration(Xs.data, Xs.row, Xs.col, st, 0.3, 0.3, bp, dp, nthreads=n)
+        trial_i[n] = time.perf_counter() - t0
+    threads_i = min(trial_i, key=trial_i.get)
+    trial_i_txt = ", ".join("%d: %.3f" % (k, v) for k, v in sorted(trial_i.items(), reverse=True))
+
+    need_gb = (nnz_full * K * itemsize + nnz_full * (12 + itemsize) + 4.0 * (N + G) * K * itemsize) / 1e9
+    whole = _mem_available_gb() >= need_gb * 1.25 + 4.0
+    points = []
+    if whole:
+        bp, dp, st = _oracle_state(orc, X, K, dtype)
+        x, row, col = X.data, X.row, X.col
+        dt, iters = _time_iterations(
+            lambda: orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=threads_i), 8.0, 3)
+        full_s, spread = dt, 0.0
+        points.append({"cells": N, "nnz": int(nnz_full), "s_per_iter": dt, "iterations": iters,
+                       "scaled_by_nnz_it_per_s": 1.0 / dt})
+        how = ("the WHOLE matrix (nnz %d; Xphi of %.1f GB materialised every iteration like the reference's), one "
+               "untimed and %d timed iterations, %.3f s/iter" % (nnz_full, nnz_full * K * itemsize / 1e9, iters, dt))
+    else:
+        for frac_target in (2.5e8, 5.0e8):             # nnz*K element budget of a sample (1/8 and 1/4 of C3)
+            Xs, rows = sample(frac_target)
+            bp, dp, st = _oracle_state(orc, Xs, K, dtype)
+            x, row, col = Xs.data, Xs.row, Xs.col
+            dt, iters = _time_iterations(
+                lambda: orc.cavi_iteration(x, row, col, st, 0.3, 0.3, bp, dp, nthreads=threads_i), 6.0, 3)
+            points.append({"cells": rows, "nnz": int(Xs.nnz), "s_per_iter": dt, "iterations": iters,
+                           "scaled_by_nnz_it_per_s": (1.0 / dt) * Xs.nnz / float(nnz_full)})
+            if Xs.nnz == nnz_full:
+                break
+        if len(points) == 2 and points[1]["nnz"] > points[0]["nnz"]:
+            alpha = (points[1]["s_per_iter"] - points[0]["s_per_iter"]) / float(points[1]["nnz"] - points[0]["nnz"])
+            gamma = points[1]["s_per_iter"] - alpha * points[1]["nnz"]
+            if alpha <= 0:                              # timing noise: fall back to plain scaling
+                alpha, gamma = points[1]["s_per_iter"] / points[1]["nnz"], 0.0
+            full_s = alpha * nnz_full + max(gamma, 0.0)
+        else:
+            full_s = points[-1]["s_per_iter"] * nnz_full / float(points[-1]["nnz"])
+        scaled = [p["scaled_by_nnz_it_per_s"] for p in points]
+        spread = (max(scaled + [1.0 / full_s]) - min(scaled + [1.0 / full_s])) * full_s
+        how = ("EXTRAPOLATED (host has %.0f GB available, the whole matrix needs %.0f): timed on the first %d and %d "
+               "of %d cells (nnz %d and %d of %d; %.3f and %.3f s/iter), linear fit in nnz to %.2f s/iter; plain "
+               "nnz-scaling of the two samples gives %.4f and %.4f it/s (spread %.0f %% of the value)"
+               % (_mem_available_gb(), need_gb, points[0]["cells"], points[-1]["cells"], N, points[0]["nnz"],
+                  points[-1]["nnz"], nnz_full, points[0]["s_per_iter"], points[-1]["s_per_iter"], full_s,
+                  scaled[0], scaled[-1], 100 * spread))
+    value = 1.0 / full_s
+
+    # (ii) fused OpenMP on the whole matrix, its team size chosen the same way
     M = orc.FusedMatrix(X, dtype)
     bp, dp, st = _oracle_state(orc, X, K, dtype)
-    trial, n = {}, cores
-    while n >= 4:
+    trial = {}
+    for n in _team_sizes(host):
         orc.fused_iteration(M, st, 0.3, 0.3, bp, dp, nthreads=n)          # warm-up of this team size
         t0 = time.perf_counter()
         orc.fused_iteration(M, st, 0.3, 0.3, bp, dp, nthreads=n)
         trial[n] = time.perf_counter() - t0
-        n //= 2
-    fused_threads = min(trial, key=trial.get) if trial else cores
+    fused_threads = min(trial, key=trial.get)
     dt_f, it_f = _time_iterations(lambda: orc.fused_iteration(M, st, 0.3, 0.3, bp, dp, nthreads=fused_threads),
                                   6.0, 10)
     return {
-        "value": value, "unit": "iterations/s", "cores": cores, "kind": "port",
-        "sample": "variant (i) numba-structure C oracle (parallel Xphi + serial scatter-adds, the "
-                  "reference's execution shape), %d threads, timed on the first %d and %d of %d cells "
-                  "(nnz %d and %d of %d; %.3f and %.3f s/iter), extrapolated by a linear fit in nnz to "
-                  "%.2f s/iter for the whole matrix; plain nnz-scaling of the two samples gives %.4f and "
-                  "%.4f it/s (spread %.0f %% of the value)"
-                  % (cores, points[0]["cells"], points[-1]["cells"], N, points[0]["nnz"], points[-1]["nnz"],
-                     nnz_full, points[0]["s_per_iter"], points[-1]["s_per_iter"], full_s, scaled[0],
-                     scaled[-1], 100 * spread),
-        "extrapolation_spread": spread, "sample_points": points,
+        "value": value, "unit": "iterations/s", "cores": threads_i, "kind": "port",
+        "host": host,
+        "sample": "variant (i) numba-structure C oracle (parallel Xphi + serial scatter-adds, the reference's "
+                  "execution shape) at %d threads -- the fastest of the team sizes tried on a 1/16 row sample "
+                  "(s per iteration: %s); the box shows %d logical CPUs, affinity %d, cgroup quota %s => %d usable -- "
+                  "on %s" % (threads_i, trial_i_txt, host["logical"], host["affinity"],
+                             "%.1f CPUs" % host["cgroup_cpu_max"] if host["cgroup_cpu_max"] else "none",
+                             host["usable"], how),
+        "whole_matrix": bool(whole), "extrapolation_spread": spread, "sample_points": points,
         "fused_openmp": {
             "value": 1.0 / dt_f, "unit": "iterations/s", "cores": fused_threads, "kind": "port",
             "sample": "variant (ii) fused OpenMP restatement (exp hoisted, no Xphi, parallel CSR + CSC "
@@ -333,7 +464,10 @@ def main():
     dtype = np.float64 if args.dtype == "f64" else np.float32
     itemsize = np.dtype(dtype).itemsize
     n_local = N // world + (1 if rank < N % world else 0)
-    X = synthetic_block(n_local, G, density, seed=42 + 1000 * rank)
+    if n_local * G * density > 2e8:     # all of C5 on few GPUs: the threaded slab generator (seconds, not minutes)
+        X = synthetic_slabs(n_local, G, density, seed=42 + 1000 * rank)
+    else:
+        X = synthetic_block(n_local, G, density, seed=42 + 1000 * rank)
 
     # the engine enqueues on a stream of its own; ShardedCAVI orders the collective with it
     eng = DeviceCAVI(n_local, G, K, dtype=dtype, device=local_rank)

@@ -508,6 +508,9 @@ import functools
 
 @functools.lru_cache(maxsize=1)
 def _bench_matrix(N, G, dens):
+    if N * G * dens > 2e8:      # all of C5: bench.py's threaded slab generator (5e8 draws in well under a minute)
+        from bench import synthetic_slabs
+        return synthetic_slabs(N, G, dens, seed=42)
     return synthetic_counts(N, G, dens, seed=42)    # bench.py's generator A, same seed
 
 
@@ -516,10 +519,8 @@ BENCH_SHAPES = [   # the workloads bench.py times (BASELINE.json configs[2] and 
     pytest.param(100000, 20000, 0.05, 20, np.float32, id="C3-f32"),
     pytest.param(125000, 25000, 0.02, 50, np.float64, id="C5share-f64"),
     pytest.param(125000, 25000, 0.02, 50, np.float32, id="C5share-f32"),
-    # ALL of C5 (BASELINE.json configs[4]: 1M x 25k, 2 %, K=50, nnz 4.95e8) on one GPU: generating the matrix
-    # takes minutes of host time, so it only runs when asked for (SCHPF_TEST_C5=1); last run: DESIGN.md 6
-    pytest.param(1000000, 25000, 0.02, 50, np.float64, id="C5whole-f64",
-                 marks=pytest.mark.skipif(not os.environ.get("SCHPF_TEST_C5"), reason="set SCHPF_TEST_C5=1 (minutes)")),
+    # ALL of C5 (BASELINE.json configs[4]: 1M x 25k, 2 %, K=50, nnz 4.95e8) on one GPU, in the default run
+    pytest.param(1000000, 25000, 0.02, 50, np.float64, id="C5whole-f64"),
 ]
 
 
