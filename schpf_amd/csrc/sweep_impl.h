@@ -527,6 +527,24 @@ struct LlhAccumulator {
     }
 };
 
+// Ablation switches of development builds (tools/devbuild.sh, DEVFLAGS=-DSCHPF_ABLATE=n; timing
+// experiments only, the results are wrong):  1 = no LDS row reads in the step loop (the registers keep the
+// prologue's rows, made opaque so that nothing is hoisted), 2 = no accumulation FMAs, 3 = no window
+// staging, 4 = no entry stream (the ring keeps its first entries), 5 = no dot product (weights = counts).
+#ifndef SCHPF_ABLATE
+#define SCHPF_ABLATE 0
+#endif
+template <typename T, int NV, int LPC>
+__device__ __forceinline__ void step_row_load(const T *__restrict__ row, int sub, T (&v)[NV * Vec16<T>::N])
+{
+    if (SCHPF_ABLATE == 1) {
+#pragma unroll
+        for (int k = 0; k < NV * Vec16<T>::N; ++k) asm volatile("" : "+v"(v[k]));
+        return;
+    }
+    load_lane<T, NV, LPC>(row, sub, v);
+}
+
 // the minor row an entry points at: LDS position in 16-byte units
 template <typename T> __device__ __forceinline__ const T *lds_row(const unsigned char *lds, unsigned off16)
 {
@@ -603,6 +621,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             __syncthreads();                       // previous window fully consumed
             const int sw0 = (L == 1 || w == w0) ? w : w + L - 1;
             const int sw1 = min(w + L, w1);
+            if (SCHPF_ABLATE != 3 || w == w0)
             for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
         }
@@ -626,7 +645,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                     // slot i was decoded one step ago: refill it; decode the NEXT step's slot.  Past the
                     // window's last step that is the next window's entry or padding: its indices
                     // are in range, the rows read with them are never used
-                    ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
+                    if (SCHPF_ABLATE != 4) ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
                     if (p + i < steps) {                               // scalar branch
                         const E cn = ring[(i + 1) % RING];
                         unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
@@ -642,19 +661,21 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                         // (inf or NaN) -- detected once, after the task, and the group is then redone by
                         // the cold path.  A small but normal s is exact enough: its largest term is a
                         // normal number.
-                        const T s0 = group_dot<T, KL, LPC>(tm, bA);
-                        const T s1 = group_dot<T, KL, LPC>(tm, bB);
+                        const T s0 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bA);
+                        const T s1 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bB);
                         if (MODE == MODE_PHI) {
                             const T q0 = fast_div(x0, s0);
                             const T q1 = fast_div(x1, s1);
+                            if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q0, bA[0], acc[0]); acc[1] = fma_t(q0, bA[KL - 1], acc[1]); } else
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
+                            step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
                             // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated
                             __builtin_amdgcn_sched_barrier(0);
+                            if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q1, bB[0], acc[0]); acc[1] = fma_t(q1, bB[KL - 1], acc[1]); } else
 #pragma unroll
                             for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
+                            step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
                         } else {
                             load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
                             load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
