@@ -22,6 +22,10 @@
 
 namespace {
 
+// internal step flag (not part of the C ABI): the sweep launch of a sharded iteration packs the gene side's
+// sums itself and raises the flag the communicator stream waits for (kernels.h ShardSync)
+constexpr unsigned SCHPF_SHARD_SYNC = 0x40000000u;
+
 thread_local std::string g_err;
 
 int fail(const char *fmt, ...)
@@ -272,7 +276,10 @@ template <typename T> struct Engine final : schpf_ctx {
     TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
     DevBuf dual_order;                              // merged launch order of both plans' tasks (or empty)
     DevBuf dual_queue;                              // persistent dual launch: {next slot, workgroups done}, self-zeroing
+    DevBuf shard_words;                             // single-launch sharded iteration (kernels.h ShardSync): 4 ints, self re-arming
     int64_t dual_slots = 0;
+    int64_t dual_gene_first = 0;                    // > 0: the order lists these many gene-side tasks before any cell-side task
+    bool stale_s_theta = false;                     // the single-launch sharded iteration sums E[theta] inside the sweep
     bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
     double gammaln_sum = 0.0;
@@ -316,6 +323,7 @@ template <typename T> struct Engine final : schpf_ctx {
         choose_config();
         const size_t s = sizeof(T);
         dual_queue.alloc(2 * sizeof(int), true, stream);
+        shard_words.alloc(4 * sizeof(int), true, stream);
         xi_s.alloc((size_t)N * s); xi_r.alloc((size_t)N * s);
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
@@ -395,9 +403,25 @@ template <typename T> struct Engine final : schpf_ctx {
         const unsigned base = (flags_ | SCHPF_SHARDED) & ~(unsigned)(SCHPF_LOCAL_GENE | SCHPF_LOCAL_CELL);
         const bool freeze = flags_ & SCHPF_FREEZE_GENES;
         const int dt = sizeof(T) == 4 ? 7 : 8;   // ncclFloat32 / ncclFloat64
+        // ONE sweep launch per iteration where the two plans can share one (same workgroup shape): gene-side tasks
+        // first, their sums packed inside the launch, the all-reduce released by a device flag while the cell-side
+        // tasks drain (kernels.h ShardSync).  Otherwise (or SCHPF_SHARD_SINGLE=0): gene-side launch, packing launch,
+        // all-reduce under the cell-side launch.
+        const bool single = env_int("SCHPF_SHARD_SINGLE", 1) && use_tile && dual_slots > 0 && dual_gene_first > 0;
         auto iterate = [&](int count) {
         for (int i = 0; i < count; ++i) {
             if (freeze) { step_local(base); step_finish(base); continue; }   // nothing to exchange
+            if (single && pending_init == 0) {
+                HIPCHK(hipEventRecord(ev_packed, stream));                   // fork: the gate may start now
+                HIPCHK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
+                HIPCHK(schpf::launch_wait_flag(shard_words.as<int>() + 2, shard_words.as<int>() + 3, comm_stream));
+                RCCLCHK(rccl().AllReduce(exchange_buf.p, exchange_buf.p, (size_t)G * K + K, dt, 0, comm, comm_stream));
+                HIPCHK(hipEventRecord(ev_reduced, comm_stream));
+                step_local(base | SCHPF_SHARD_SYNC);
+                HIPCHK(hipStreamWaitEvent(stream, ev_reduced, 0));
+                step_finish(base | SCHPF_SHARD_SYNC);
+                continue;
+            }
             step_local(base | SCHPF_LOCAL_GENE);
             HIPCHK(hipEventRecord(ev_packed, stream));
             HIPCHK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
@@ -791,6 +815,7 @@ template <typename T> struct Engine final : schpf_ctx {
         // Both sweeps of an iteration in one launch (kernels.h launch_tile_sweep_dual) when the two
         // plans agree on the workgroup shape: slots = all tasks of both plans, longest first
         dual_slots = 0;
+        dual_gene_first = 0;
         dual_order.release();
         if (env_int("SCHPF_DUAL", 1) && tcell.threads == tgene.threads && tcell.packed == tgene.packed) {
             const auto &hc = tcell.host, &hg = tgene.host;
@@ -805,6 +830,13 @@ template <typename T> struct Engine final : schpf_ctx {
                 const schpf::TilePlanHost *both[2] = {&hc, &hg};
                 const int per_cu = tcell.lds_bytes > 80 * 1024 ? 1 : 2;
                 schpf::xcd_launch_order(both, 2, n_xcd, n_cu() / n_xcd * per_cu, ord);
+            } else if (expect_sharded) {
+                // a row shard's iteration in one launch: every gene-side task before the first cell-side task, so
+                // that the gene side's sums can leave for the all-reduce while the cell side is still running
+                ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
+                for (int32_t t : hg.task_order) ord.push_back(~t);
+                for (int32_t t : hc.task_order) ord.push_back(t);
+                dual_gene_first = (int64_t)hg.task_order.size();
             } else {
                 ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
                 size_t i = 0, j = 0;   // merge of two lists already sorted by decreasing work
@@ -1150,6 +1182,13 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         need_coo();
         refresh_tables();
+        if (stale_s_theta && !(flags_ & SCHPF_SHARD_SYNC)) {
+            // the single-launch sharded iterations before this one summed E[theta] inside their sweeps: bring
+            // s_theta and the tail of the exchange buffer up to date for the paths that read them
+            HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), upd_blocks(N), K, s_theta.as<double>(),
+                                               exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
+            stale_s_theta = false;
+        }
         const bool freeze = flags_ & SCHPF_FREEZE_GENES;
         const bool sharded = flags_ & SCHPF_SHARDED;
         const bool only_gene = flags_ & SCHPF_LOCAL_GENE, only_cell = flags_ & SCHPF_LOCAL_CELL;
@@ -1171,8 +1210,25 @@ template <typename T> struct Engine final : schpf_ctx {
                 queue = dual_queue.as<int>();
                 resident = n_cu() * (lds > 80 * 1024 ? 1 : 2);
             }
+            schpf::ShardSync<T> sync{};
+            if (flags_ & SCHPF_SHARD_SYNC) {
+                // the gene side's sums are packed inside the launch (kernels.h ShardSync); a few compute units stay
+                // free for the all-reduce that starts while the cell-side tasks are still running
+                queue = dual_queue.as<int>();
+                const int per_cu = lds > 80 * 1024 ? 1 : 2;
+                resident = std::max(1, n_cu() - env_int("SCHPF_SHARD_RESERVE_CUS", 16)) * per_cu;
+                sync.words = shard_words.as<int>();
+                sync.n_gene_tasks = (int)dual_gene_first;
+                sync.n_packers = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)env_int("SCHPF_SHARD_PACKERS", 16),
+                                                                             dual_gene_first, (int64_t)resident, dual_slots}));
+                sync.pfirst = tgene.pfirst.as<int>(); sync.pcount = tgene.pcount.as<int>();
+                sync.pstride = tgene.host.pstride;
+                sync.n = G; sync.K = K; sync.KP = KP;
+                sync.out = exchange_buf.as<T>();
+                sync.colpart = colpart_cell.as<double>(); sync.colpart_nb = upd_blocks(N);
+            }
             HIPCHK(schpf::launch_tile_sweep_dual<T>(ac, ag, dual_order.as<int>(), NV, LPC, tcell.packed ? 1 : 0,
-                                                    dual_slots, tcell.threads, lds, queue, resident, stream));
+                                                    dual_slots, tcell.threads, lds, queue, resident, sync, stream));
             tm.stop();
         } else if (pending_init == 0) {
             if (do_gene && !freeze) {
@@ -1186,7 +1242,7 @@ template <typename T> struct Engine final : schpf_ctx {
                 tm.stop();
             }
         }
-        if (sharded && !freeze && pending_init != 1 && do_gene) {
+        if (sharded && !freeze && pending_init != 1 && do_gene && !(flags_ & SCHPF_SHARD_SYNC)) {
             // fixed-order reduction of this rank's gene-side partials into the exchange buffer
             if (use_tile)
                 HIPCHK(schpf::launch_combine_strided<T>(tgene.partials.as<T>(), tgene.pfirst.as<int>(),
@@ -1215,6 +1271,7 @@ template <typename T> struct Engine final : schpf_ctx {
         // default ordering on a small problem: no reduce launches (BASELINE C2: 2 of its 5 launches)
         const bool fuse = !sharded && !freeze && !simultaneous && !cells_first && env_int("SCHPF_FUSE_SUMS", 1) &&
                           (int64_t)upd_blocks(N) * K <= 16384 && (int64_t)upd_blocks(G) * K <= 16384;
+        const bool in_sweep_sums = (flags_ & SCHPF_SHARD_SYNC) != 0;   // E[theta]'s column sums are taken inside the sweep launch
         if (!fuse && sums_stale) {   // s_theta / s_beta from the partials the last fused iteration left
             HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), upd_blocks(N), K, s_theta.as<double>(),
                                                exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
@@ -1266,9 +1323,12 @@ template <typename T> struct Engine final : schpf_ctx {
             u.colsum_part = colpart_cell.as<double>();
             const int nb = upd_blocks(N);
             HIPCHK(schpf::launch_gamma_update(u, src, nb, stream));
-            if (!fuse)
+            if (in_sweep_sums) stale_s_theta = true;
+            else if (!fuse) {
                 HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
                                                    exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
+                stale_s_theta = false;
+            }
         }
         };
         if (cells_first) { cell_update(); gene_update(); }   // minibatch order: theta first, beta from the NEW theta

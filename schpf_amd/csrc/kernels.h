@@ -49,6 +49,59 @@ template <typename T> struct TileArgs {
     int n_tasks, resident;
 };
 
+// Single-launch sharded iteration (sweep_impl.h tile_sweep_dual_kernel): the launch order lists every
+// gene-side task before the first cell-side task; the last `n_packers` workgroups to finish a gene-side task
+// wait for the stragglers, reduce the gene side's partial rows into the exchange buffer (the work of
+// combine_strided_kernel, same order) + the K local sums of E[theta] into its tail, and the last of them raises
+// words[2] -- which a one-wave kernel on the communicator's stream is waiting for (launch_wait_flag): the
+// all-reduce then starts while the remaining workgroups are still draining the cell-side tasks.
+// words: [0] gene-side tasks finished, [1] packers finished, [2] "exchange buffer ready", [3] time-out marker.
+template <typename T> struct ShardSync {
+    int *words;                  // nullptr: plain dual launch
+    int n_gene_tasks, n_packers;
+    const int *pfirst, *pcount;  // the gene side's partial rows (UpdateArgs SRC_STRIDED)
+    int64_t pstride;
+    int n, K, KP;                // genes, factors, padded row
+    T *out;                      // exchange buffer [n * K + K]
+    const double *colpart;       // [colpart_nb, K] per-block column sums of E[theta] (the last cell-side update's)
+    int colpart_nb;
+};
+
+// Fixed-order sum of n values `stride` apart, four loads in flight (the partial rows of one
+// major row live far apart in HBM/L2; a rolled loop would pay one memory latency per term).
+template <typename T> __device__ __forceinline__ double sum_strided(const T *__restrict__ p, int n, size_t stride)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 0;
+    for (; c + 4 <= n; c += 4) {
+        const T v0 = p[0], v1 = p[stride], v2 = p[2 * stride], v3 = p[3 * stride];
+        s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        p += 4 * stride;
+    }
+    for (; c < n; ++c, p += stride) s0 += (double)*p;
+    return (s0 + s1) + (s2 + s3);
+}
+
+// Column sums of per-block partials [nblocks, K] in ONE fixed order that does not depend on who computes them
+// (colsum_reduce_kernel, or a packer workgroup of the single-launch sharded sweep): factor k is summed by
+// VJ = max(1, 1024 / K) virtual lanes -- lane j takes the blocks j, j + VJ, ... through eight interleaved
+// accumulators -- and the lanes' values are then added in lane order.
+__host__ __device__ inline int colsum_lanes(int K) { return K >= 1024 ? 1 : 1024 / K; }
+__device__ __forceinline__ double colsum_lane(const double *__restrict__ part, int nblocks, int K, int k, int j, int VJ)
+{
+    double q[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int b = j;
+    for (; b + 7 * VJ < nblocks; b += 8 * VJ) {      // eight loads in flight: the partials sit in L2
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = part[(size_t)(b + i * VJ) * K + k];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] += v[i];
+    }
+    for (; b < nblocks; b += VJ) q[0] += part[(size_t)b * K + k];
+    return ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+}
+
 template <typename T> struct UpdateArgs {
     int n, K, KP, rows_per_block;
     const T *partials;          // SRC_PARTIALS: [n_chunks, KP]
@@ -97,7 +150,9 @@ hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, in
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
                                   int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
-                                  hipStream_t st);
+                                  const ShardSync<T> &sync, hipStream_t st);
+// one wave that returns when *flag != 0 (and zeroes it), or after ~a second (then *timeout_marker = 1)
+hipError_t launch_wait_flag(int *flag, int *timeout_marker, hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);

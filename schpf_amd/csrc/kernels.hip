@@ -39,21 +39,6 @@ __device__ __forceinline__ double dev_digamma(double x)
     return log(x) - 0.5 * r - z * p - num / den;
 }
 
-// Fixed-order sum of n values `stride` apart, four loads in flight (the partial rows of one
-// major row live far apart in HBM/L2; a rolled loop would pay one memory latency per term).
-template <typename T> __device__ __forceinline__ double sum_strided(const T *__restrict__ p, int n, size_t stride)
-{
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int c = 0;
-    for (; c + 4 <= n; c += 4) {
-        const T v0 = p[0], v1 = p[stride], v2 = p[2 * stride], v3 = p[3 * stride];
-        s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
-        p += 4 * stride;
-    }
-    for (; c < n; ++c, p += stride) s0 += (double)*p;
-    return (s0 + s1) + (s2 + s3);
-}
-
 // ------------------------------------------------------- fused Gamma update + tables
 // One thread per (row, factor).  Replaces, for one side (theta or beta) and in one
 // launch: compute_loading_shape_update (hpf_numba.py:128-156; here only the fixed-order
@@ -166,31 +151,20 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
     if (t < K) a.colsum_part[(size_t)blockIdx.x * K + t] = sC[t];
 }
 
-// colsum_part [nblocks, K] -> out[K] (double), fixed order.  One workgroup per factor: every
-// thread has its (few) loads in flight at once, then a fixed-shape tree in LDS -- one memory
-// round trip instead of a serial walk over the blocks.
+// colsum_part [nblocks, K] -> out[K] (double), in the fixed order of kernels.h colsum_lane.  One workgroup per
+// factor: every virtual lane has its loads in flight at once, then lane 0 adds the lanes' values in turn.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double *__restrict__ part, int nblocks,
                                                              int K, double *__restrict__ out,
                                                              void *mirror, int mirror_is_f32)
 {
-    __shared__ double red[256];
+    __shared__ double red[1024];
     const int t = threadIdx.x, k = blockIdx.x;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = t;
-    for (; b + 768 < nblocks; b += 1024) {
-        const double v0 = part[(size_t)b * K + k], v1 = part[(size_t)(b + 256) * K + k];
-        const double v2 = part[(size_t)(b + 512) * K + k], v3 = part[(size_t)(b + 768) * K + k];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-    }
-    for (; b < nblocks; b += 256) s0 += part[(size_t)b * K + k];
-    red[t] = (s0 + s1) + (s2 + s3);
+    const int VJ = colsum_lanes(K);
+    for (int j = t; j < VJ; j += 256) red[j] = colsum_lane(part, nblocks, K, k, j, VJ);
     __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if (t < m) red[t] += red[t + m];
-        __syncthreads();
-    }
     if (t == 0) {
-        const double tot = red[0];
+        double tot = 0.0;
+        for (int j = 0; j < VJ; ++j) tot += red[j];
         out[k] = tot;
         if (mirror) {
             if (mirror_is_f32) ((float *)mirror)[k] = (float)tot;
@@ -483,6 +457,29 @@ hipError_t launch_combine_strided(const T *partials, const int *pfirst, const in
 {
     hipLaunchKernelGGL((combine_strided_kernel<T>), dim3(blocks_for((int64_t)n * K)), dim3(256), 0, st,
                        partials, pfirst, pcount, pstride, n, K, KP, out);
+    return hipGetLastError();
+}
+
+// The communicator stream's gate of the single-launch sharded iteration (kernels.h ShardSync): one wave polls
+// ONE word with relaxed agent-scope loads (the producer published with an agent-scope release before
+// its flag store), re-arms it and leaves; what follows on the stream (the RCCL all-reduce) starts at a kernel
+// boundary, which is an acquire.  The spin is bounded: a protocol error must surface as a failing
+// test (the marker word), never as a hung GPU.
+__global__ __launch_bounds__(64) void wait_flag_kernel(int *flag, int *timeout_marker)
+{
+    if (threadIdx.x != 0) return;
+    for (unsigned spins = 0; spins < (1u << 22); ++spins) {     // ~1 s
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_store(timeout_marker, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+hipError_t launch_wait_flag(int *flag, int *timeout_marker, hipStream_t st)
+{
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, st, flag, timeout_marker);
     return hipGetLastError();
 }
 

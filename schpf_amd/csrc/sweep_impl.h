@@ -848,6 +848,37 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
         a.queue[1] = 0;
     }
 }
+// The packing share of one of the last workgroups to finish a gene-side task (kernels.h ShardSync): slice
+// `rank` of `n_packers` of the n * K sums, each the fixed-order sum of the row's partial rows
+// (combine_strided_kernel's arithmetic), and -- rank 0 -- the K local column sums of E[theta].
+template <typename T>
+__device__ __forceinline__ void shard_pack_slice(const ShardSync<T> &y, const T *__restrict__ partials, int rank,
+                                                 double *scratch)
+{
+    const int64_t items = (int64_t)y.n * y.K;
+    const int64_t per = (items + y.n_packers - 1) / y.n_packers;
+    const int64_t lo = per * rank, hi = lo + per < items ? lo + per : items;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int row = (int)(i / y.K), k = (int)(i - (int64_t)row * y.K);
+        y.out[i] = (T)sum_strided(partials + (size_t)y.pfirst[row] * y.KP + k, y.pcount[row],
+                                  (size_t)y.pstride * y.KP);
+    }
+    if (rank == 0) {
+        // the order of colsum_reduce_kernel (kernels.h colsum_lane): VJ virtual lanes per factor, VJ * K <= 1024
+        const int K = y.K, VJ = colsum_lanes(K);
+        for (int v = (int)threadIdx.x; v < VJ * K; v += (int)blockDim.x) {
+            const int j = v / K, k = v - j * K;
+            scratch[v] = colsum_lane(y.colpart, y.colpart_nb, K, k, j, VJ);
+        }
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < K; k += (int)blockDim.x) {
+            double tot = 0.0;
+            for (int j = 0; j < VJ; ++j) tot += scratch[j * K + k];
+            y.out[items + k] = (T)tot;
+        }
+    }
+}
+
 // Both sweeps of an iteration in ONE launch (they read the same old tables and write disjoint
 // partials): order[slot] = task of the cell-side plan, or ~task of the gene-side plan, merged
 // longest-first.  One launch has one tail instead of two and the two task pools fill each
@@ -859,20 +890,74 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 // longest-first list is balanced by who is free, not by the dispatcher's round-robin.  queue[1]
 // counts the workgroups that have found the list empty; the last one zeroes both words for the
 // next launch.
+//
+// y.words != nullptr: the iteration of a row shard (kernels.h ShardSync) -- gene-side tasks first, their
+// sums packed for the all-reduce by the last workgroups that finish one, inside this launch.
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
                                                               const int *__restrict__ order, int n_slots,
-                                                              int *__restrict__ queue)
+                                                              int *__restrict__ queue, ShardSync<T> y)
 {
     __shared__ int next_slot;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int slot = blockIdx.x;
+    // sharded: EVERY slot comes from the counter, the first one too -- a task is then always held by a
+    // workgroup that is running, which is what lets the packers wait for the stragglers (at most
+    // n_packers - 1 gene-side tasks are unfinished when a packer starts to wait, all of them drawn)
+    const int drawn_by_launch = y.words ? 0 : (int)gridDim.x;
+    if (y.words) {
+        if (threadIdx.x == 0) next_slot = atomicAdd(&queue[0], 1);
+        __syncthreads();
+        slot = next_slot;
+        __syncthreads();
+    }
     for (;;) {
         const int code = order[slot];
         if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a0, code);
         else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a1, ~code);
+        if (y.words && code < 0) {
+            // publish this task's partial rows (every wave has issued its stores: drain, meet, ONE agent-scope
+            // release), then count it done; the last n_packers arrivals become packers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int arrived = __hip_atomic_fetch_add(&y.words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                int rank = arrived - (y.n_gene_tasks - y.n_packers) - 1;      // >= 0: packer `rank`
+                if (rank >= 0) {
+                    bool ok = false;
+                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {   // bounded (~1 s): see wait_flag_kernel
+                        if (__hip_atomic_load(&y.words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= y.n_gene_tasks) { ok = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (!ok) { __hip_atomic_store(&y.words[3], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // drop this CU's stale lines of the partials
+                }
+                next_slot = rank;
+            }
+            __syncthreads();
+            const int rank = next_slot;
+            __syncthreads();
+            if (rank >= 0) {
+                shard_pack_slice<T>(y, a1.partials, rank, reinterpret_cast<double *>(lds_raw));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const int packed = __hip_atomic_fetch_add(&y.words[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+                    if (packed == y.n_packers) {      // every slice is in memory: re-arm the counters, raise the flag
+                        __hip_atomic_store(&y.words[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&y.words[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&y.words[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
         if (!queue) return;
         __syncthreads();                                   // the window and next_slot are free again
-        if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&queue[0], 1);
+        if (threadIdx.x == 0) next_slot = drawn_by_launch + atomicAdd(&queue[0], 1);
         __syncthreads();
         slot = next_slot;
         if (slot >= n_slots) break;
@@ -937,7 +1022,8 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
 
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
-                                int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
+                                int threads, size_t lds_bytes, int *queue, int resident, const ShardSync<T> &sync,
+                                hipStream_t st)
 {
     if (lds_bytes > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};
@@ -948,23 +1034,27 @@ static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, co
             if (e != hipSuccess) { raised = 0; return e; }
         }
     }
-    if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
+    if (sync.words) {   // sharded: always through the counter (see the kernel), and room for the packers' scratch
+        if (!queue) return hipErrorInvalidValue;
+        if (resident > n_slots) resident = (int)n_slots;
+        if (lds_bytes < 1024 * sizeof(double)) lds_bytes = 1024 * sizeof(double);
+    } else if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
     const unsigned grid = queue ? (unsigned)resident : (unsigned)n_slots;
     hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>), dim3(grid), dim3((unsigned)threads), lds_bytes,
-                       st, a0, a1, order, (int)n_slots, queue);
+                       st, a0, a1, order, (int)n_slots, queue, sync);
     return hipGetLastError();
 }
 template <typename T, int NV, int LPC>
 static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int packed,
                                 int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
-                                hipStream_t st)
+                                const ShardSync<T> &sync, hipStream_t st)
 {
     if (n_slots == 0) return hipSuccess;
     if (threads <= 512)
-        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
-                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
-    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
-                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
+        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st)
+                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st);
+    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st)
+                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st);
 }
 
 // ------------------------------------------------------------------------ launchers
@@ -1042,10 +1132,10 @@ hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, in
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
                                   int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
-                                  hipStream_t st)
+                                  const ShardSync<T> &sync, hipStream_t st)
 {
     SCHPF_DISPATCH_TILE(nv, lpc,
-                        (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, queue, resident, st)))
+                        (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, queue, resident, sync, st)))
 }
 
 }  // namespace schpf

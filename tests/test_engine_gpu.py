@@ -889,16 +889,33 @@ def test_fit_over_devices_reproduces_reference_trace(amd, monkeypatch, fname, dt
         assert_allclose(got.vi_rate, g[name + "_rate"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
 
 
-def test_library_rccl_one_rank_equals_plain_steps(amd, oracle):
+def load_shard_engine(amd, X, K, dtype, st, a, c, bp, dp):
+    """load_engine for a rank of a sharded fit: hint_sharded() before the upload, as ThreadedShards and
+    bench.py do -- the plans' launch order then lists the gene-side tasks first and schpf_steps_sharded
+    runs the single-launch iteration (kernels.h ShardSync)."""
+    eng = amd.DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype)
+    eng.hint_sharded()
+    eng.upload(X)
+    eng.set_hypers(a, c, bp, dp)
+    eng.set_gamma("xi", st.xi_shape, st.xi_rate)
+    eng.set_gamma("theta", st.theta_shape, st.theta_rate)
+    eng.set_gamma("eta", st.eta_shape, st.eta_rate)
+    eng.set_gamma("beta", st.beta_shape, st.beta_rate)
+    return eng
+
+
+@pytest.mark.parametrize("hinted", [False, True])
+def test_library_rccl_one_rank_equals_plain_steps(amd, oracle, hinted):
     """The collective inside the library (schpf_comm_init / schpf_steps_sharded / schpf_loss_terms_all,
     RCCL bound at run time to the copy already in the process): a one-rank communicator on the GPU
     box.  The sharded iteration -- two sweep launches, packing, all-reduce on the communicator's
-    stream ordered by events, update from the exchange buffer -- must equal the oracle."""
+    stream ordered by events, update from the exchange buffer; or, hinted, ONE sweep launch that packs
+    the gene side's sums itself and releases the all-reduce through a device flag -- must equal the oracle."""
     from schpf_amd.sharded import NativeShard
     X = synthetic_counts(700, 500, 0.06, seed=17)
     K, a, c = 20, 0.3, 0.3
     bp, dp, st = random_state(oracle, X, K, np.float64, seed=6)
-    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+    with (load_shard_engine if hinted else load_engine)(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
         shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)
         shard.steps(2)
         shard.step(simultaneous=True)
@@ -909,6 +926,48 @@ def test_library_rccl_one_rank_equals_plain_steps(amd, oracle):
         want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
                                              st.beta_shape, st.beta_rate)
         assert_allclose(shard.mean_negative_pois_llh(), want, rtol=1e-11)
+
+
+@only_plans("tile", "half")
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_single_launch_sharded_iteration_matches_oracle_and_two_launch_path(amd, oracle, plan_kind, dtype, graph,
+                                                                             monkeypatch):
+    """The single-launch iteration of a row shard (gene-side tasks first, their sums packed by the last
+    workgroups to finish one, the all-reduce gated by a device flag on the communicator's stream) at a size
+    with several rounds of tasks per compute unit, eager and as a captured hipGraph, through mode switches
+    (simultaneous / frozen genes / plain single-GPU steps in between, which read the sums the sweep no longer
+    keeps up to date): equal to the oracle, and BITWISE equal to the two-launch path -- the packing inside
+    the sweep does combine_strided_kernel's arithmetic in its order."""
+    from schpf_amd.sharded import NativeShard
+    monkeypatch.setenv("SCHPF_GRAPH_SHARDED", graph)
+    X = synthetic_counts(20000, 8000, 0.015, seed=12)        # > 256 tasks per side: the counter is really used
+    K, a, c = 20, 0.3, 0.3
+    f32 = np.dtype(dtype) == np.float32
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=4)
+    seq = [(1, {}), (4, {}), (4, {}), (1, {"simultaneous": True}), (2, {"freeze_genes": True}), (3, {})]
+    states = {}
+    for single in ("1", "0"):
+        monkeypatch.setenv("SCHPF_SHARD_SINGLE", single)
+        ref = st.copy()
+        with load_shard_engine(amd, X, K, dtype, ref, a, c, bp, dp) as eng:
+            shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)
+            done = 0
+            for n, flags in seq:
+                shard.steps(n, **flags)
+                for _ in range(n):
+                    oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp, **flags)
+                done += n
+                compare_state(eng, ref, rtol=(2e-5 * done) if f32 else 1e-10)
+            eng.step()                                        # a plain step: needs s_theta brought up to date
+            oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp)
+            shard.steps(2)
+            for _ in range(2):
+                oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp)
+            compare_state(eng, ref, rtol=(2e-5 * (done + 3)) if f32 else 1e-10)
+            states[single] = [eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")]
+    for (s1, r1), (s0, r0) in zip(states["1"], states["0"]):
+        assert np.array_equal(s1, s0) and np.array_equal(r1, r0)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
