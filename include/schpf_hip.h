@@ -180,6 +180,16 @@ int schpf_synchronize(schpf_ctx *ctx);
  * sweeps then run as two launches, and the plans of a small row block are cut into tasks that fill the
  * GPU once per launch instead of once per pair of launches). */
 int schpf_hint_sharded(schpf_ctx *ctx, int on);
+
+/* Minibatch CAVI without re-uploads (the reference re-slices X each iteration: X[batch_ix], scHPF_.py:643-650,
+ * with util.minibatch_ix_generator :218-231).  schpf_keep_rows(ctx, 1) BEFORE schpf_upload_coo makes the engine
+ * keep, beside its plans, a (row, col)-sorted copy of the matrix in HBM.  schpf_upload_rows(batch, source, rows, n)
+ * then makes `batch`'s matrix the rows rows[0..n) of `source`'s (local cell i = source cell rows[i]; n must be the
+ * ncells `batch` was created with, same device, dtype, ngenes, nfactors): gathered and planned on the device,
+ * nothing crosses PCIe but the n row numbers.  A batch engine has no loss constants: schpf_loss_terms on it fails,
+ * evaluate the loss on the source. */
+int schpf_keep_rows(schpf_ctx *ctx, int on);
+int schpf_upload_rows(schpf_ctx *ctx, schpf_ctx *source, const int32_t *rows, int n_rows);
 int schpf_comm_unique_id(void *out128);
 int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int world);
 int schpf_comm_destroy(schpf_ctx *ctx);
@@ -228,15 +238,19 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
 /* Same for the tile plan (LDS-staged sweep): per stored nonzero the major/minor/val, the partial
  * row (task * groups_per_block + group) it accumulates into and its task; pfirst/pcount[n_major];
  * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task}.
- * ring <= 1: window schedule with win_rows rows per window; ring >= 3: ring schedule with `ring`
- * slots of slot_bytes (a multiple of 1024 * waves_per_block; table rows are 160 bytes here) -- the
- * hook then also checks that every entry of an epoch points into a slot readable in that epoch;
- * ring <= -2: the half-window schedule with -ring slots of slot_bytes (a multiple of 16). */
+ * ring <= 1: window schedule with win_rows rows per window; ring <= -2: the half-window schedule with
+ * -ring slots of slot_bytes (a multiple of 16; table rows are 160 bytes here) -- the hook then also
+ * checks that every entry of an epoch points into a slot readable in that epoch. */
 int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *minor, const float *val,
                             int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
                             int target_tasks, int ring, int slot_bytes, int32_t *out_major,
                             int32_t *out_minor, float *out_val, int32_t *out_prow, int32_t *out_task,
                             int32_t *out_pfirst, int32_t *out_pcount, int64_t stats[6]);
+
+/* Measurement hook: the first n doubles of the engine's per-wave output buffer (the loss sweep's partial
+ * sums; development builds with -DSCHPF_ABLATE=9 leave each persistent workgroup's finishing time there,
+ * tools/tail_study.py). */
+int schpf_debug_read_wave_out(schpf_ctx *ctx, double *out, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,8 @@ SIGNATURES = {
     "schpf_loss_terms": [_vp, _dblp, _dblp, _i64p],
     "schpf_synchronize": [_vp],
     "schpf_hint_sharded": [_vp, _int],
+    "schpf_keep_rows": [_vp, _int],
+    "schpf_upload_rows": [_vp, _vp, _vp, _int],
     "schpf_comm_unique_id": [_vp],
     "schpf_comm_init": [_vp, _vp, _int, _int],
     "schpf_comm_destroy": [_vp],
@@ -60,6 +62,7 @@ SIGNATURES = {
     "schpf_profile_read": [_vp, _dblp, _i64p],
     "schpf_plan_info": [_vp, _i64p],
     "schpf_upload_info": [_vp, _i64p],
+    "schpf_debug_read_wave_out": [_vp, _vp, _i64],
     "schpf_coo_marginals": [_i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp],
     "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64p],

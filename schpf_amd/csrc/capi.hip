@@ -22,10 +22,6 @@
 
 namespace {
 
-// internal step flag (not part of the C ABI): the sweep launch of a sharded iteration packs the gene side's
-// sums itself and raises the flag the communicator stream waits for (kernels.h ShardSync)
-constexpr unsigned SCHPF_SHARD_SYNC = 0x40000000u;
-
 thread_local std::string g_err;
 
 int fail(const char *fmt, ...)
@@ -226,6 +222,8 @@ struct schpf_ctx {
     virtual void steps(unsigned flags, int n) = 0;
     virtual void hypers_changed() = 0;
     virtual void hint_sharded(int on) = 0;
+    virtual void keep_rows(int on) = 0;
+    virtual void upload_rows(schpf_ctx *source, const int32_t *rows, int n_rows) = 0;
     virtual void steps_sharded(unsigned flags, int n) = 0;
     virtual void loss_terms_all(double *llh, double *gl, int64_t *nnz) = 0;
     // cells sharded over GPUs: this rank's RCCL communicator and the stream its collectives run on
@@ -254,6 +252,7 @@ struct schpf_ctx {
     }
     virtual void exchange(void **p, int64_t *count) = 0;
     virtual void loss_terms(double *llh, double *gl, int64_t *nnz) = 0;
+    virtual void read_wave_out(double *out, int64_t n) = 0;
     virtual void plan_info(int64_t info[16]) = 0;
     virtual void upload_info(int64_t info[4]) = 0;
     double a = 0.3, c = 0.3, bp = 1.0, dp = 1.0;
@@ -276,10 +275,7 @@ template <typename T> struct Engine final : schpf_ctx {
     TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
     DevBuf dual_order;                              // merged launch order of both plans' tasks (or empty)
     DevBuf dual_queue;                              // persistent dual launch: {next slot, workgroups done}, self-zeroing
-    DevBuf shard_words;                             // single-launch sharded iteration (kernels.h ShardSync): 4 ints, self re-arming
     int64_t dual_slots = 0;
-    int64_t dual_gene_first = 0;                    // > 0: the order lists these many gene-side tasks before any cell-side task
-    bool stale_s_theta = false;                     // the single-launch sharded iteration sums E[theta] inside the sweep
     bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
     double gammaln_sum = 0.0;
@@ -302,10 +298,46 @@ template <typename T> struct Engine final : schpf_ctx {
     // two reduce launches of an iteration are skipped; s_theta / s_beta are then brought up to date
     // only when a path that reads them comes along (sums_stale)
     bool sums_stale = false;
-    bool expect_sharded = false;        // schpf_hint_sharded: the sweeps will run as two launches
+    // Minibatch CAVI without re-uploads (scHPF_.py:643-650): an engine that was told to keep_rows() holds, beside
+    // its plans, the matrix once more as a (row, col)-sorted device copy; a batch engine's upload_rows(source,
+    // rows) gathers its rows from there and builds its plans from device arrays -- no host slicing, no PCIe.
+    bool want_rows = false, rows_packed_ok = true;
+    DevBuf rows_ptr, rows_col, rows_val;            // int64[N + 1], int32[nnz], float[nnz]; host copy of rows_ptr: tcell.host.mptr
+    bool have_loss_constants = true;                // false after upload_rows (no lgamma sum / stored-zero list for a batch)
+    bool expect_sharded = false;        // schpf_hint_sharded: a rank of a sharded fit (gene-side sums leave for an all-reduce)
     static constexpr int UPD_BLOCKS = 2048;
     static constexpr size_t TABLE_PAD = 256 * 1024;
 
+    // The COO's index arrays start their trip over PCIe on a helper thread and a copy stream of its own
+    // while the calling thread is still validating / converting the values and sampling the block loads:
+    // the copy does not care whether the indices are in range, only the plan kernels do (and they run after
+    // the validation has passed).
+    struct EarlyIndexCopy {
+        DevBuf d_row, d_col;
+        std::thread worker;
+        std::string error;
+        double seconds = 0.0;
+        bool started = false;
+        void start(int device, int64_t n, const int32_t *row, const int32_t *col)
+        {
+            d_row.alloc((size_t)n * 4); d_col.alloc((size_t)n * 4);
+            started = true;
+            worker = std::thread([this, device, n, row, col] {
+                const double t0 = now_s();
+                hipStream_t cs = nullptr;
+                hipError_t e = hipSetDevice(device);
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+                if (e == hipSuccess && n > 0) e = hipMemcpyAsync(d_col.p, col, (size_t)n * 4, hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess && n > 0) e = hipMemcpyAsync(d_row.p, row, (size_t)n * 4, hipMemcpyHostToDevice, cs);
+                if (e == hipSuccess) e = hipStreamSynchronize(cs);
+                if (cs) (void)hipStreamDestroy(cs);
+                if (e != hipSuccess) error = std::string("H2D of the COO indices failed: ") + hipGetErrorString(e);
+                seconds = now_s() - t0;
+            });
+        }
+        void join() { if (worker.joinable()) worker.join(); }
+        ~EarlyIndexCopy() { join(); }
+    };
     Engine(int device_, void *stream_, int dtype_, int N_, int G_, int K_)
     {
         device = device_; dtype = dtype_; N = N_; G = G_; K = K_;
@@ -323,7 +355,6 @@ template <typename T> struct Engine final : schpf_ctx {
         choose_config();
         const size_t s = sizeof(T);
         dual_queue.alloc(2 * sizeof(int), true, stream);
-        shard_words.alloc(4 * sizeof(int), true, stream);
         xi_s.alloc((size_t)N * s); xi_r.alloc((size_t)N * s);
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
@@ -338,7 +369,8 @@ template <typename T> struct Engine final : schpf_ctx {
         scalars.alloc(8 * sizeof(double), true, stream);
     }
     void hypers_changed() override { drop_graph(); }
-    void hint_sharded(int on) override { expect_sharded = on != 0; }   // a, c, bp, dp are kernel arguments of the captured launches
+    void hint_sharded(int on) override { expect_sharded = on != 0; }
+    void keep_rows(int on) override { want_rows = on != 0; }   // a, c, bp, dp are kernel arguments of the captured launches
     void drop_graph()
     {
         for (CachedGraph &g : graphs) {
@@ -403,25 +435,9 @@ template <typename T> struct Engine final : schpf_ctx {
         const unsigned base = (flags_ | SCHPF_SHARDED) & ~(unsigned)(SCHPF_LOCAL_GENE | SCHPF_LOCAL_CELL);
         const bool freeze = flags_ & SCHPF_FREEZE_GENES;
         const int dt = sizeof(T) == 4 ? 7 : 8;   // ncclFloat32 / ncclFloat64
-        // ONE sweep launch per iteration where the two plans can share one (same workgroup shape): gene-side tasks
-        // first, their sums packed inside the launch, the all-reduce released by a device flag while the cell-side
-        // tasks drain (kernels.h ShardSync).  Otherwise (or SCHPF_SHARD_SINGLE=0): gene-side launch, packing launch,
-        // all-reduce under the cell-side launch.
-        const bool single = env_int("SCHPF_SHARD_SINGLE", 1) && use_tile && dual_slots > 0 && dual_gene_first > 0;
         auto iterate = [&](int count) {
         for (int i = 0; i < count; ++i) {
             if (freeze) { step_local(base); step_finish(base); continue; }   // nothing to exchange
-            if (single && pending_init == 0) {
-                HIPCHK(hipEventRecord(ev_packed, stream));                   // fork: the gate may start now
-                HIPCHK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
-                HIPCHK(schpf::launch_wait_flag(shard_words.as<int>() + 2, shard_words.as<int>() + 3, comm_stream));
-                RCCLCHK(rccl().AllReduce(exchange_buf.p, exchange_buf.p, (size_t)G * K + K, dt, 0, comm, comm_stream));
-                HIPCHK(hipEventRecord(ev_reduced, comm_stream));
-                step_local(base | SCHPF_SHARD_SYNC);
-                HIPCHK(hipStreamWaitEvent(stream, ev_reduced, 0));
-                step_finish(base | SCHPF_SHARD_SYNC);
-                continue;
-            }
             step_local(base | SCHPF_LOCAL_GENE);
             HIPCHK(hipEventRecord(ev_packed, stream));
             HIPCHK(hipStreamWaitEvent(comm_stream, ev_packed, 0));
@@ -589,23 +605,46 @@ template <typename T> struct Engine final : schpf_ctx {
 
     // Both tile plans built by device passes over the uploaded COO (plan_device.hip): same plans,
     // bit for bit, as build_tiles(); SCHPF_DEVICE_PLAN=0 selects the host builder.
-    void build_tiles_device(const int32_t *row, const int32_t *col, const float *val, bool packed_ok)
+    void build_tiles_device(const int32_t *row, const int32_t *col, const float *val, bool packed_ok,
+                            EarlyIndexCopy &early)
     {
         const double t0 = now_s();
         int ranges[2] = {0, 0}, half[2] = {-1, -1};
         if (!choose_ranges(row, col, ranges, half)) { ranges[0] = ranges[1] = 0; half[0] = half[1] = -1; }
-        const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
-                               sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         bool rc_sorted = true, cr_sorted = true;
         schpf::coo_order_flags(nnz, row, col, rc_sorted, cr_sorted);
-        DevBuf d_row, d_col, d_val;
-        d_row.alloc((size_t)nnz * 4); d_col.alloc((size_t)nnz * 4); d_val.alloc((size_t)nnz * 4);
-        if (nnz > 0) {
-            HIPCHK(hipMemcpyAsync(d_row.p, row, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_col.p, col, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
-            HIPCHK(hipMemcpyAsync(d_val.p, val, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
-        }
+        DevBuf d_val;
+        d_val.alloc((size_t)nnz * 4);
+        if (nnz > 0) HIPCHK(hipMemcpyAsync(d_val.p, val, (size_t)nnz * 4, hipMemcpyHostToDevice, stream));
+        early.join();                                  // the indices went up beside the validation pass
+        if (!early.error.empty()) throw HipError(early.error);
         const double t1 = now_s();
+        plans_from_device_coo(early.d_row, early.d_col, d_val, rc_sorted, cr_sorted, packed_ok, ranges, half);
+        // constant term of the loss, sum lgamma(x + 1) (hpf_numba.py:49-50), while the values are still resident:
+        // no second trip of the values over PCIe
+        gammaln_partial_sums(d_val.as<float>());
+        gammaln_on_device = true;
+        if (want_rows) {   // the (row, col)-sorted copy minibatches gather their rows from
+            rows_col.alloc((size_t)nnz * 4); rows_val.alloc((size_t)nnz * 4);
+            HIPCHK(schpf::launch_gather_by_order(tcell.order_identity ? nullptr : tcell.order_dev.as<int>(),
+                                                 static_cast<const int *>(early.d_col.p), d_val.as<float>(), nnz, rows_col.as<int>(),
+                                                 rows_val.as<float>(), stream));
+            upload(rows_ptr, tcell.host.mptr, stream);
+            rows_packed_ok = packed_ok;
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        if (env_int("SCHPF_VERBOSE", 0))
+            fprintf(stderr, "[schpf_hip]   tile plans on the device: ranges + H2D of the values %.3f s (indices: %.3f s on the "
+                    "helper thread, from the start of the upload), both plans %.3f s (%.2f GB entries)\n",
+                    t1 - t0, early.seconds, now_s() - t1, (tcell.entries.bytes + tgene.entries.bytes) * 1e-9);
+    }
+
+    // both tile plans from a COO that is already in HBM
+    void plans_from_device_coo(const DevBuf &d_row, const DevBuf &d_col, const DevBuf &d_val, bool rc_sorted,
+                               bool cr_sorted, bool packed_ok, const int ranges[2], const int half[2])
+    {
+        const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
+                               sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         for (int side = 0; side < 2; ++side) {
             TileDev &td = side == 0 ? tcell : tgene;
             void *e = nullptr, *s = nullptr, *o = nullptr;
@@ -623,9 +662,47 @@ template <typename T> struct Engine final : schpf_ctx {
             finish_tile(td);
         }
         build_dual_order();
-        if (env_int("SCHPF_VERBOSE", 0))
-            fprintf(stderr, "[schpf_hip]   tile plans on the device: H2D of the COO %.3f s, both plans %.3f s (%.2f GB entries)\n",
-                    t1 - t0, now_s() - t1, (tcell.entries.bytes + tgene.entries.bytes) * 1e-9);
+    }
+
+    // This engine's matrix := the rows `rows` (in that order) of `source`'s, gathered on the device
+    void upload_rows(schpf_ctx *source_, const int32_t *rows, int n_rows) override
+    {
+        Engine<T> *src = dynamic_cast<Engine<T> *>(source_);
+        if (!src) throw std::invalid_argument("the source engine must have this engine's dtype");
+        if (!src->rows_ptr.p || !src->have_coo) throw std::logic_error("the source keeps no rows (schpf_keep_rows before its upload)");
+        if (src->device != device) throw std::invalid_argument("source and batch engine must be on one device");
+        if (src->G != G || src->K != K) throw std::invalid_argument("source and batch engine differ in genes or factors");
+        if (n_rows != N) throw std::invalid_argument("n_rows must be the number of cells the batch engine was created with");
+        if (!want_tile) throw std::invalid_argument("upload_rows needs the tile plan");
+        const std::vector<int64_t> &sp = src->tcell.host.mptr;
+        std::vector<int64_t> dp((size_t)n_rows + 1, 0);
+        for (int i = 0; i < n_rows; ++i) {
+            if (rows[i] < 0 || rows[i] >= src->N) throw std::invalid_argument("batch row out of range");
+            dp[(size_t)i + 1] = dp[(size_t)i] + (sp[(size_t)rows[i] + 1] - sp[(size_t)rows[i]]);
+        }
+        nnz = dp[(size_t)n_rows];
+        std::vector<int32_t> rv(rows, rows + n_rows);
+        DevBuf d_rows, d_dp, d_row, d_col, d_val;
+        upload(d_rows, rv, stream);
+        upload(d_dp, dp, stream);
+        d_row.alloc((size_t)nnz * 4); d_col.alloc((size_t)nnz * 4); d_val.alloc((size_t)nnz * 4);
+        HIPCHK(schpf::launch_gather_rows(d_rows.as<int>(), n_rows, src->rows_ptr.as<int64_t>(), src->rows_col.as<int>(),
+                                         src->rows_val.as<float>(), d_dp.as<int64_t>(), d_row.as<int>(), d_col.as<int>(),
+                                         d_val.as<float>(), stream));
+        use_tile = true;
+        cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
+        const int ranges[2] = {0, 0}, half[2] = {-1, -1};
+        // rows in batch order with their columns ascending: sorted by (row, col) already
+        plans_from_device_coo(d_row, d_col, d_val, true, false, src->rows_packed_ok, ranges, half);
+        wave_out.alloc((size_t)std::max<int64_t>(tcell.n_wave_out, 1) * sizeof(double), true, stream);
+        HIPCHK(hipStreamSynchronize(stream));
+        n_rounded = 0; n_zero = 0;
+        zero_row.release(); zero_col.release();
+        have_loss_constants = false;      // no lgamma sum, no stored-zero list: the loss is the source engine's business
+        have_coo = true;
+        pending_init = 0;
+        drop_graph();
+        eager_since_upload = false;
     }
 
     // Workgroup shape of the tile sweep.  One 1024-thread workgroup per CU with a 152 KiB window
@@ -705,6 +782,9 @@ template <typename T> struct Engine final : schpf_ctx {
                                                                expect_sharded ? 4 : 6, 1.12, 32, expect_sharded);
         if (c.ranges[0] <= 0 || c.ranges[1] <= 0) return false;
         for (int s = 0; s < 2; ++s) { ranges[s] = c.ranges[s]; half[s] = c.half[s] ? 1 : 0; }
+        // exploration: fix the ranges by hand, keep the model's schedules (tools/explore.py)
+        if (env_int("SCHPF_RANGES_CELL", 0) > 0) ranges[0] = env_int("SCHPF_RANGES_CELL", 0);
+        if (env_int("SCHPF_RANGES_GENE", 0) > 0) ranges[1] = env_int("SCHPF_RANGES_GENE", 0);
         if (env_int("SCHPF_VERBOSE", 0))
             fprintf(stderr, "[schpf_hip]   task ranges from the list-schedule model: cell %d (%s), gene %d (%s), %.3f ms\n",
                     ranges[0], half[0] ? "half windows" : "windows", ranges[1], half[1] ? "half windows" : "windows",
@@ -815,7 +895,6 @@ template <typename T> struct Engine final : schpf_ctx {
         // Both sweeps of an iteration in one launch (kernels.h launch_tile_sweep_dual) when the two
         // plans agree on the workgroup shape: slots = all tasks of both plans, longest first
         dual_slots = 0;
-        dual_gene_first = 0;
         dual_order.release();
         if (env_int("SCHPF_DUAL", 1) && tcell.threads == tgene.threads && tcell.packed == tgene.packed) {
             const auto &hc = tcell.host, &hg = tgene.host;
@@ -830,13 +909,6 @@ template <typename T> struct Engine final : schpf_ctx {
                 const schpf::TilePlanHost *both[2] = {&hc, &hg};
                 const int per_cu = tcell.lds_bytes > 80 * 1024 ? 1 : 2;
                 schpf::xcd_launch_order(both, 2, n_xcd, n_cu() / n_xcd * per_cu, ord);
-            } else if (expect_sharded) {
-                // a row shard's iteration in one launch: every gene-side task before the first cell-side task, so
-                // that the gene side's sums can leave for the all-reduce while the cell side is still running
-                ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
-                for (int32_t t : hg.task_order) ord.push_back(~t);
-                for (int32_t t : hc.task_order) ord.push_back(t);
-                dual_gene_first = (int64_t)hg.task_order.size();
             } else {
                 ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
                 size_t i = 0, j = 0;   // merge of two lists already sorted by decreasing work
@@ -853,6 +925,16 @@ template <typename T> struct Engine final : schpf_ctx {
         }
     }
 
+    bool gammaln_on_device = false;
+    DevBuf gammaln_part;
+    void gammaln_partial_sums(const float *d_values)
+    {
+        const int nb = 512;
+        if (!gammaln_part.p) gammaln_part.alloc(nb * sizeof(double));
+        HIPCHK(schpf::launch_gammaln_sum(d_values, nnz, gammaln_part.as<double>(), nb, stream));
+        HIPCHK(schpf::launch_sum_doubles(gammaln_part.as<double>(), nb, scalars.as<double>() + 1, stream));
+    }
+
     static double now_s()
     {
         return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -864,6 +946,9 @@ template <typename T> struct Engine final : schpf_ctx {
         const double t_start = now_s();
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
         if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
+        EarlyIndexCopy early;
+        const bool device_plans = want_tile && env_int("SCHPF_DEVICE_PLAN", 1);
+        if (device_plans) early.start(device, nnz_, row, col);
         schpf::BigVec<float> v((size_t)nnz_);   // no serial zero-fill: written by the threaded pass below
         bool packed_ok = true;
         n_rounded = 0;
@@ -929,7 +1014,7 @@ template <typename T> struct Engine final : schpf_ctx {
         cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
         int64_t n_out;
         if (use_tile) {
-            if (env_int("SCHPF_DEVICE_PLAN", 1)) build_tiles_device(row, col, v.data(), packed_ok);
+            if (device_plans) build_tiles_device(row, col, v.data(), packed_ok, early);
             else build_tiles(row, col, v.data());
             n_out = tcell.n_wave_out;
         } else {
@@ -943,16 +1028,17 @@ template <typename T> struct Engine final : schpf_ctx {
 
         const double t_plans = now_s();
         // constant term of the loss: sum lgamma(x + 1)   (hpf_numba.py:49-50)
-        DevBuf dv, part;
-        upload(dv, v, stream);
-        const int nb = 512;
-        part.alloc(nb * sizeof(double));
-        HIPCHK(schpf::launch_gammaln_sum(dv.as<float>(), nnz, part.as<double>(), nb, stream));
-        HIPCHK(schpf::launch_sum_doubles(part.as<double>(), nb, scalars.as<double>() + 1, stream));
+        DevBuf dv;
+        if (!gammaln_on_device) {          // host-built plans: the values go up once more for it
+            upload(dv, v, stream);
+            gammaln_partial_sums(dv.as<float>());
+        }
+        gammaln_on_device = false;
         HIPCHK(hipMemcpyAsync(&gammaln_sum, scalars.as<double>() + 1, sizeof(double), hipMemcpyDeviceToHost,
                               stream));
         HIPCHK(hipStreamSynchronize(stream));
         have_coo = true;
+        have_loss_constants = true;
         pending_init = 0;
         drop_graph();
         eager_since_upload = false;
@@ -1182,13 +1268,6 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         need_coo();
         refresh_tables();
-        if (stale_s_theta && !(flags_ & SCHPF_SHARD_SYNC)) {
-            // the single-launch sharded iterations before this one summed E[theta] inside their sweeps: bring
-            // s_theta and the tail of the exchange buffer up to date for the paths that read them
-            HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), upd_blocks(N), K, s_theta.as<double>(),
-                                               exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
-            stale_s_theta = false;
-        }
         const bool freeze = flags_ & SCHPF_FREEZE_GENES;
         const bool sharded = flags_ & SCHPF_SHARDED;
         const bool only_gene = flags_ & SCHPF_LOCAL_GENE, only_cell = flags_ & SCHPF_LOCAL_CELL;
@@ -1210,25 +1289,8 @@ template <typename T> struct Engine final : schpf_ctx {
                 queue = dual_queue.as<int>();
                 resident = n_cu() * (lds > 80 * 1024 ? 1 : 2);
             }
-            schpf::ShardSync<T> sync{};
-            if (flags_ & SCHPF_SHARD_SYNC) {
-                // the gene side's sums are packed inside the launch (kernels.h ShardSync); a few compute units stay
-                // free for the all-reduce that starts while the cell-side tasks are still running
-                queue = dual_queue.as<int>();
-                const int per_cu = lds > 80 * 1024 ? 1 : 2;
-                resident = std::max(1, n_cu() - env_int("SCHPF_SHARD_RESERVE_CUS", 16)) * per_cu;
-                sync.words = shard_words.as<int>();
-                sync.n_gene_tasks = (int)dual_gene_first;
-                sync.n_packers = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)env_int("SCHPF_SHARD_PACKERS", 16),
-                                                                             dual_gene_first, (int64_t)resident, dual_slots}));
-                sync.pfirst = tgene.pfirst.as<int>(); sync.pcount = tgene.pcount.as<int>();
-                sync.pstride = tgene.host.pstride;
-                sync.n = G; sync.K = K; sync.KP = KP;
-                sync.out = exchange_buf.as<T>();
-                sync.colpart = colpart_cell.as<double>(); sync.colpart_nb = upd_blocks(N);
-            }
             HIPCHK(schpf::launch_tile_sweep_dual<T>(ac, ag, dual_order.as<int>(), NV, LPC, tcell.packed ? 1 : 0,
-                                                    dual_slots, tcell.threads, lds, queue, resident, sync, stream));
+                                                    dual_slots, tcell.threads, lds, queue, resident, stream));
             tm.stop();
         } else if (pending_init == 0) {
             if (do_gene && !freeze) {
@@ -1242,7 +1304,7 @@ template <typename T> struct Engine final : schpf_ctx {
                 tm.stop();
             }
         }
-        if (sharded && !freeze && pending_init != 1 && do_gene && !(flags_ & SCHPF_SHARD_SYNC)) {
+        if (sharded && !freeze && pending_init != 1 && do_gene) {
             // fixed-order reduction of this rank's gene-side partials into the exchange buffer
             if (use_tile)
                 HIPCHK(schpf::launch_combine_strided<T>(tgene.partials.as<T>(), tgene.pfirst.as<int>(),
@@ -1271,7 +1333,6 @@ template <typename T> struct Engine final : schpf_ctx {
         // default ordering on a small problem: no reduce launches (BASELINE C2: 2 of its 5 launches)
         const bool fuse = !sharded && !freeze && !simultaneous && !cells_first && env_int("SCHPF_FUSE_SUMS", 1) &&
                           (int64_t)upd_blocks(N) * K <= 16384 && (int64_t)upd_blocks(G) * K <= 16384;
-        const bool in_sweep_sums = (flags_ & SCHPF_SHARD_SYNC) != 0;   // E[theta]'s column sums are taken inside the sweep launch
         if (!fuse && sums_stale) {   // s_theta / s_beta from the partials the last fused iteration left
             HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), upd_blocks(N), K, s_theta.as<double>(),
                                                exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
@@ -1323,12 +1384,9 @@ template <typename T> struct Engine final : schpf_ctx {
             u.colsum_part = colpart_cell.as<double>();
             const int nb = upd_blocks(N);
             HIPCHK(schpf::launch_gamma_update(u, src, nb, stream));
-            if (in_sweep_sums) stale_s_theta = true;
-            else if (!fuse) {
+            if (!fuse)
                 HIPCHK(schpf::launch_colsum_reduce(colpart_cell.as<double>(), nb, K, s_theta.as<double>(),
                                                    exchange_buf.as<T>() + (size_t)G * K, sizeof(T) == 4, stream));
-                stale_s_theta = false;
-            }
         }
         };
         if (cells_first) { cell_update(); gene_update(); }   // minibatch order: theta first, beta from the NEW theta
@@ -1344,6 +1402,8 @@ template <typename T> struct Engine final : schpf_ctx {
     void loss_terms(double *llh, double *gl, int64_t *nnz_out) override
     {
         need_coo();
+        if (!have_loss_constants)
+            throw std::logic_error("this engine holds gathered batch rows (schpf_upload_rows): evaluate the loss on the source");
         refresh_tables();
         ScopedTimer tm(prof, stream, 2);
         run_sweep(0, schpf::MODE_LLH);
@@ -1362,6 +1422,13 @@ template <typename T> struct Engine final : schpf_ctx {
         *llh = n_zero > 0 ? h[0] - h[2] : h[0];
         *gl = gammaln_sum;
         *nnz_out = nnz;
+    }
+
+    void read_wave_out(double *out, int64_t n) override
+    {
+        if (n < 0 || (size_t)n * sizeof(double) > wave_out.bytes) throw std::invalid_argument("n out of range");
+        HIPCHK(hipMemcpyAsync(out, wave_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
     }
 
     void upload_info(int64_t info[4]) override
@@ -1661,6 +1728,13 @@ int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int worl
 }
 int schpf_comm_destroy(schpf_ctx *ctx) { CTX_CALL(ctx->comm_destroy()); }
 int schpf_hint_sharded(schpf_ctx *ctx, int on) { CTX_CALL(ctx->hint_sharded(on)); }
+int schpf_keep_rows(schpf_ctx *ctx, int on) { CTX_CALL(ctx->keep_rows(on)); }
+int schpf_upload_rows(schpf_ctx *ctx, schpf_ctx *source, const int32_t *rows, int n_rows)
+{
+    if (!source) return fail("source is NULL");
+    if (!rows && n_rows > 0) return fail("rows is NULL");
+    CTX_CALL(ctx->upload_rows(source, rows, n_rows));
+}
 int schpf_steps_sharded(schpf_ctx *ctx, unsigned flags, int n)
 {
     if (n < 0) return fail("n must be >= 0");
@@ -1694,6 +1768,11 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
 }
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]) { CTX_CALL(ctx->plan_info(info)); }
 int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]) { CTX_CALL(ctx->upload_info(info)); }
+int schpf_debug_read_wave_out(schpf_ctx *ctx, double *out, int64_t n)
+{
+    if (!out) return fail("out is NULL");
+    CTX_CALL(ctx->read_wave_out(out, n));
+}
 
 int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind,
                         int ncells, int ngenes, double *row_sums, double *col_sums)

@@ -49,24 +49,6 @@ template <typename T> struct TileArgs {
     int n_tasks, resident;
 };
 
-// Single-launch sharded iteration (sweep_impl.h tile_sweep_dual_kernel): the launch order lists every
-// gene-side task before the first cell-side task; the last `n_packers` workgroups to finish a gene-side task
-// wait for the stragglers, reduce the gene side's partial rows into the exchange buffer (the work of
-// combine_strided_kernel, same order) + the K local sums of E[theta] into its tail, and the last of them raises
-// words[2] -- which a one-wave kernel on the communicator's stream is waiting for (launch_wait_flag): the
-// all-reduce then starts while the remaining workgroups are still draining the cell-side tasks.
-// words: [0] gene-side tasks finished, [1] packers finished, [2] "exchange buffer ready", [3] time-out marker.
-template <typename T> struct ShardSync {
-    int *words;                  // nullptr: plain dual launch
-    int n_gene_tasks, n_packers;
-    const int *pfirst, *pcount;  // the gene side's partial rows (UpdateArgs SRC_STRIDED)
-    int64_t pstride;
-    int n, K, KP;                // genes, factors, padded row
-    T *out;                      // exchange buffer [n * K + K]
-    const double *colpart;       // [colpart_nb, K] per-block column sums of E[theta] (the last cell-side update's)
-    int colpart_nb;
-};
-
 // Fixed-order sum of n values `stride` apart, four loads in flight (the partial rows of one
 // major row live far apart in HBM/L2; a rolled loop would pay one memory latency per term).
 template <typename T> __device__ __forceinline__ double sum_strided(const T *__restrict__ p, int n, size_t stride)
@@ -83,7 +65,7 @@ template <typename T> __device__ __forceinline__ double sum_strided(const T *__r
 }
 
 // Column sums of per-block partials [nblocks, K] in ONE fixed order that does not depend on who computes them
-// (colsum_reduce_kernel, or a packer workgroup of the single-launch sharded sweep): factor k is summed by
+// (colsum_reduce_kernel today; a sweep epilogue could take the sums over): factor k is summed by
 // VJ = max(1, 1024 / K) virtual lanes -- lane j takes the blocks j, j + VJ, ... through eight interleaved
 // accumulators -- and the lanes' values are then added in lane order.
 __host__ __device__ inline int colsum_lanes(int K) { return K >= 1024 ? 1 : 1024 / K; }
@@ -150,9 +132,7 @@ hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, in
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
                                   int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
-                                  const ShardSync<T> &sync, hipStream_t st);
-// one wave that returns when *flag != 0 (and zeroes it), or after ~a second (then *timeout_marker = 1)
-hipError_t launch_wait_flag(int *flag, int *timeout_marker, hipStream_t st);
+                                  hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);
@@ -163,6 +143,15 @@ template <typename T>
 hipError_t launch_combine_strided(const T *partials, const int *pfirst, const int *pcount, int64_t pstride, int n,
                                   int K, int KP, T *out, hipStream_t st);
 hipError_t launch_sum_doubles(const double *v, int64_t n, double *out, hipStream_t st);
+// minibatch rows from a resident row-sorted copy (capi.hip keep_rows / upload_rows):
+//   out_col/val[j] = col/val[order[j]]  (order == nullptr: identity copy)
+hipError_t launch_gather_by_order(const int *order, const int *col, const float *val, int64_t nnz, int *out_col,
+                                  float *out_val, hipStream_t st);
+//   batch row i = source row rows[i]: its (col, val) run src_ptr[rows[i]] .. src_ptr[rows[i] + 1] goes to
+//   dst_ptr[i] ..., with local row index i
+hipError_t launch_gather_rows(const int *rows, int n_rows, const int64_t *src_ptr, const int *src_col,
+                              const float *src_val, const int64_t *dst_ptr, int *out_row, int *out_col,
+                              float *out_val, hipStream_t st);
 hipError_t launch_gammaln_sum(const float *x, int64_t n, double *block_out, int nblocks, hipStream_t st);
 template <typename T>
 hipError_t launch_zero_rate_sum(const int *row, const int *col, int64_t n, const T *et, const T *eb, int K, int KP,

@@ -9,6 +9,7 @@
 // and the stateless operator mirrors.  The sweep kernels are in sweep_impl.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "kernels.h"
 
@@ -460,26 +461,49 @@ hipError_t launch_combine_strided(const T *partials, const int *pfirst, const in
     return hipGetLastError();
 }
 
-// The communicator stream's gate of the single-launch sharded iteration (kernels.h ShardSync): one wave polls
-// ONE word with relaxed agent-scope loads (the producer published with an agent-scope release before
-// its flag store), re-arms it and leaves; what follows on the stream (the RCCL all-reduce) starts at a kernel
-// boundary, which is an acquire.  The spin is bounded: a protocol error must surface as a failing
-// test (the marker word), never as a hung GPU.
-__global__ __launch_bounds__(64) void wait_flag_kernel(int *flag, int *timeout_marker)
+__global__ __launch_bounds__(256) void gather_by_order_kernel(const int *__restrict__ order, const int *__restrict__ col,
+                                                              const float *__restrict__ val, int64_t nnz,
+                                                              int *__restrict__ out_col, float *__restrict__ out_val)
 {
-    if (threadIdx.x != 0) return;
-    for (unsigned spins = 0; spins < (1u << 22); ++spins) {     // ~1 s
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        __builtin_amdgcn_s_sleep(8);
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * 256) {
+        const int64_t src = order ? (int64_t)order[j] : j;
+        out_col[j] = col[src];
+        out_val[j] = val[src];
     }
-    __hip_atomic_store(timeout_marker, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-hipError_t launch_wait_flag(int *flag, int *timeout_marker, hipStream_t st)
+hipError_t launch_gather_by_order(const int *order, const int *col, const float *val, int64_t nnz, int *out_col,
+                                  float *out_val, hipStream_t st)
 {
-    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, st, flag, timeout_marker);
+    if (nnz <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((nnz + 255) / 256 < 65536 ? (nnz + 255) / 256 : 65536);
+    hipLaunchKernelGGL(gather_by_order_kernel, dim3(grid), dim3(256), 0, st, order, col, val, nnz, out_col, out_val);
+    return hipGetLastError();
+}
+// one wavefront per batch row: coalesced copy of the row's run
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int *__restrict__ rows, int n_rows,
+                                                          const int64_t *__restrict__ src_ptr, const int *__restrict__ src_col,
+                                                          const float *__restrict__ src_val, const int64_t *__restrict__ dst_ptr,
+                                                          int *__restrict__ out_row, int *__restrict__ out_col,
+                                                          float *__restrict__ out_val)
+{
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n_rows; i += gridDim.x * 4) {
+        const int64_t s0 = src_ptr[rows[i]], len = src_ptr[rows[i] + 1] - s0, d0 = dst_ptr[i];
+        for (int64_t j = lane; j < len; j += 64) {
+            out_row[d0 + j] = i;
+            out_col[d0 + j] = src_col[s0 + j];
+            out_val[d0 + j] = src_val[s0 + j];
+        }
+    }
+}
+hipError_t launch_gather_rows(const int *rows, int n_rows, const int64_t *src_ptr, const int *src_col,
+                              const float *src_val, const int64_t *dst_ptr, int *out_row, int *out_col,
+                              float *out_val, hipStream_t st)
+{
+    if (n_rows <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n_rows + 3) / 4 < 65536 ? (n_rows + 3) / 4 : 65536);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, st, rows, n_rows, src_ptr, src_col, src_val,
+                       dst_ptr, out_row, out_col, out_val);
     return hipGetLastError();
 }
 

@@ -732,47 +732,22 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                             for (int k = 0; k < KL; ++k) acc[k] += (T)(wgt * d[k]);
                         }
                     } else {
-                        // narrow rows: both nonzeros of the step in flight; wide rows: one at a time
-                        if (PAIR) {
-                            T b0[KL], b1[KL];
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i0), sub, b0);
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i1), sub, b1);
-                            const T x0 = (T)xf0, x1 = (T)xf1;
-                            const T s0 = group_dot<T, KL, LPC>(tm, b0);
-                            const T s1 = group_dot<T, KL, LPC>(tm, b1);
-                            if (MODE == MODE_PHI) {
-                                const bool ok0 = s0 >= tiny, ok1 = s1 >= tiny;
-                                const T q0 = safe_weight(x0, s0, ok0), q1 = safe_weight(x1, s1, ok1);
-                                any_bad |= (x0 > T(0) && !ok0) || (x1 > T(0) && !ok1);
-#pragma unroll
-                                for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, b1[k], fma_t(q0, b0[k], acc[k]));
-                            } else if (LPC == 1) {
-                                if (x0 > T(0)) llh += (double)x0 * log((double)s0) - (double)s0;
-                                if (x1 > T(0)) llh += (double)x1 * log((double)s1) - (double)s1;
-                            } else {
-                                // every lane of the group knows s0 and s1: lane 0 takes the log of the
-                                // first nonzero, lane 1 of the second (the f64 log is the costly part)
-                                const T sm = (sub & 1) ? s1 : s0;
-                                const T xm = (sub & 1) ? x1 : x0;
-                                if (sub < 2 && xm > T(0)) llh += (double)xm * log((double)sm) - (double)sm;
-                            }
-                        } else {
+                        // wide rows (two of them do not fit the registers): one nonzero at a time.  As in the
+                        // pipelined loop there is no test of the normaliser: an underflowed s poisons the
+                        // group's accumulators (inf / NaN), which is detected once after the task
 #pragma unroll 1
-                            for (int u = 0; u < 2; ++u) {
-                                T b[KL];
-                                load_lane<T, NV, LPC>(lds_row<T>(lds_raw, u ? i1 : i0), sub, b);
-                                const T x = (T)(u ? xf1 : xf0);
-                                const T s = group_dot<T, KL, LPC>(tm, b);
-                                if (MODE == MODE_PHI) {
-                                    const bool ok = s >= tiny;
-                                    const T q = safe_weight(x, s, ok);
-                                    any_bad |= x > T(0) && !ok;
+                        for (int u = 0; u < 2; ++u) {
+                            T b[KL];
+                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, u ? i1 : i0), sub, b);
+                            const T x = (T)(u ? xf1 : xf0);
+                            const T s = group_dot<T, KL, LPC>(tm, b);
+                            if (MODE == MODE_PHI) {
+                                const T q = fast_div(x, s);
 #pragma unroll
-                                    for (int k = 0; k < KL; ++k) acc[k] = fma_t(q, b[k], acc[k]);
-                                } else {
-                                    // wide rows: lane 0 of the group keeps the group's share
-                                    if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
-                                }
+                                for (int k = 0; k < KL; ++k) acc[k] = fma_t(q, b[k], acc[k]);
+                            } else {
+                                // lane 0 of the group keeps the group's share
+                                if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
                             }
                         }
                     }
@@ -799,7 +774,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         return;
     }
     T *out_row = a.partials + ((size_t)task * gpb + g) * KP;
-    if (MODE == MODE_PHI && PIPE) {   // non-finite accumulators <=> some normaliser underflowed (see the loop)
+    if (MODE == MODE_PHI) {   // non-finite accumulators <=> some normaliser underflowed (see the loops)
         T probe = T(0);
 #pragma unroll
         for (int k = 0; k < KL; ++k) probe = fma_t(acc[k], T(0), probe);   // 0, or NaN
@@ -848,37 +823,6 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
         a.queue[1] = 0;
     }
 }
-// The packing share of one of the last workgroups to finish a gene-side task (kernels.h ShardSync): slice
-// `rank` of `n_packers` of the n * K sums, each the fixed-order sum of the row's partial rows
-// (combine_strided_kernel's arithmetic), and -- rank 0 -- the K local column sums of E[theta].
-template <typename T>
-__device__ __forceinline__ void shard_pack_slice(const ShardSync<T> &y, const T *__restrict__ partials, int rank,
-                                                 double *scratch)
-{
-    const int64_t items = (int64_t)y.n * y.K;
-    const int64_t per = (items + y.n_packers - 1) / y.n_packers;
-    const int64_t lo = per * rank, hi = lo + per < items ? lo + per : items;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const int row = (int)(i / y.K), k = (int)(i - (int64_t)row * y.K);
-        y.out[i] = (T)sum_strided(partials + (size_t)y.pfirst[row] * y.KP + k, y.pcount[row],
-                                  (size_t)y.pstride * y.KP);
-    }
-    if (rank == 0) {
-        // the order of colsum_reduce_kernel (kernels.h colsum_lane): VJ virtual lanes per factor, VJ * K <= 1024
-        const int K = y.K, VJ = colsum_lanes(K);
-        for (int v = (int)threadIdx.x; v < VJ * K; v += (int)blockDim.x) {
-            const int j = v / K, k = v - j * K;
-            scratch[v] = colsum_lane(y.colpart, y.colpart_nb, K, k, j, VJ);
-        }
-        __syncthreads();
-        for (int k = (int)threadIdx.x; k < K; k += (int)blockDim.x) {
-            double tot = 0.0;
-            for (int j = 0; j < VJ; ++j) tot += scratch[j * K + k];
-            y.out[items + k] = (T)tot;
-        }
-    }
-}
-
 // Both sweeps of an iteration in ONE launch (they read the same old tables and write disjoint
 // partials): order[slot] = task of the cell-side plan, or ~task of the gene-side plan, merged
 // longest-first.  One launch has one tail instead of two and the two task pools fill each
@@ -890,78 +834,30 @@ __device__ __forceinline__ void shard_pack_slice(const ShardSync<T> &y, const T 
 // longest-first list is balanced by who is free, not by the dispatcher's round-robin.  queue[1]
 // counts the workgroups that have found the list empty; the last one zeroes both words for the
 // next launch.
-//
-// y.words != nullptr: the iteration of a row shard (kernels.h ShardSync) -- gene-side tasks first, their
-// sums packed for the all-reduce by the last workgroups that finish one, inside this launch.
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
                                                               const int *__restrict__ order, int n_slots,
-                                                              int *__restrict__ queue, ShardSync<T> y)
+                                                              int *__restrict__ queue)
 {
     __shared__ int next_slot;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int slot = blockIdx.x;
-    // sharded: EVERY slot comes from the counter, the first one too -- a task is then always held by a
-    // workgroup that is running, which is what lets the packers wait for the stragglers (at most
-    // n_packers - 1 gene-side tasks are unfinished when a packer starts to wait, all of them drawn)
-    const int drawn_by_launch = y.words ? 0 : (int)gridDim.x;
-    if (y.words) {
-        if (threadIdx.x == 0) next_slot = atomicAdd(&queue[0], 1);
-        __syncthreads();
-        slot = next_slot;
-        __syncthreads();
-    }
+#if SCHPF_ABLATE == 9
+    if (threadIdx.x == 0 && blockIdx.x == 0) a0.wave_out[gridDim.x] = (double)wall_clock64();   // launch start
+#endif
     for (;;) {
         const int code = order[slot];
         if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a0, code);
         else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a1, ~code);
-        if (y.words && code < 0) {
-            // publish this task's partial rows (every wave has issued its stores: drain, meet, ONE agent-scope
-            // release), then count it done; the last n_packers arrivals become packers
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int arrived = __hip_atomic_fetch_add(&y.words[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                int rank = arrived - (y.n_gene_tasks - y.n_packers) - 1;      // >= 0: packer `rank`
-                if (rank >= 0) {
-                    bool ok = false;
-                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {   // bounded (~1 s): see wait_flag_kernel
-                        if (__hip_atomic_load(&y.words[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= y.n_gene_tasks) { ok = true; break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    if (!ok) { __hip_atomic_store(&y.words[3], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // drop this CU's stale lines of the partials
-                }
-                next_slot = rank;
-            }
-            __syncthreads();
-            const int rank = next_slot;
-            __syncthreads();
-            if (rank >= 0) {
-                shard_pack_slice<T>(y, a1.partials, rank, reinterpret_cast<double *>(lds_raw));
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const int packed = __hip_atomic_fetch_add(&y.words[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-                    if (packed == y.n_packers) {      // every slice is in memory: re-arm the counters, raise the flag
-                        __hip_atomic_store(&y.words[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&y.words[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&y.words[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-        }
         if (!queue) return;
         __syncthreads();                                   // the window and next_slot are free again
-        if (threadIdx.x == 0) next_slot = drawn_by_launch + atomicAdd(&queue[0], 1);
+        if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&queue[0], 1);
         __syncthreads();
         slot = next_slot;
         if (slot >= n_slots) break;
     }
+#if SCHPF_ABLATE == 9   /* tail study: when each persistent workgroup ran dry (wave_out is unused by MODE_PHI) */
+    if (threadIdx.x == 0) a0.wave_out[blockIdx.x] = (double)wall_clock64();
+#endif
     if (threadIdx.x == 0 && atomicAdd(&queue[1], 1) == (int)gridDim.x - 1) {
         queue[0] = 0;
         queue[1] = 0;
@@ -1022,8 +918,7 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
 
 template <typename T, int NV, int LPC, int MAXT, bool PACK>
 static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
-                                int threads, size_t lds_bytes, int *queue, int resident, const ShardSync<T> &sync,
-                                hipStream_t st)
+                                int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
 {
     if (lds_bytes > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};
@@ -1034,27 +929,23 @@ static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, co
             if (e != hipSuccess) { raised = 0; return e; }
         }
     }
-    if (sync.words) {   // sharded: always through the counter (see the kernel), and room for the packers' scratch
-        if (!queue) return hipErrorInvalidValue;
-        if (resident > n_slots) resident = (int)n_slots;
-        if (lds_bytes < 1024 * sizeof(double)) lds_bytes = 1024 * sizeof(double);
-    } else if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
+    if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
     const unsigned grid = queue ? (unsigned)resident : (unsigned)n_slots;
     hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>), dim3(grid), dim3((unsigned)threads), lds_bytes,
-                       st, a0, a1, order, (int)n_slots, queue, sync);
+                       st, a0, a1, order, (int)n_slots, queue);
     return hipGetLastError();
 }
 template <typename T, int NV, int LPC>
 static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int packed,
                                 int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
-                                const ShardSync<T> &sync, hipStream_t st)
+                                hipStream_t st)
 {
     if (n_slots == 0) return hipSuccess;
     if (threads <= 512)
-        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st)
-                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st);
-    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st)
-                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, sync, st);
+        return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                      : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
+    return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                  : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
 }
 
 // ------------------------------------------------------------------------ launchers
@@ -1132,10 +1023,10 @@ hipError_t launch_tile_sweep(const TileArgs<T> &a, int nv, int lpc, int mode, in
 template <typename T>
 hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int nv, int lpc,
                                   int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
-                                  const ShardSync<T> &sync, hipStream_t st)
+                                  hipStream_t st)
 {
     SCHPF_DISPATCH_TILE(nv, lpc,
-                        (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, queue, resident, sync, st)))
+                        (launch_dual_t<T, NV, LPC>(a0, a1, order, packed, n_slots, threads, lds_bytes, queue, resident, st)))
 }
 
 }  // namespace schpf

@@ -107,6 +107,18 @@ class DeviceCAVI(object):
                           "rounded (relative error <= 6e-8); counts are stored as float32 on the device"
                           % (info["rounded"], info["nnz"]), RuntimeWarning, stacklevel=stacklevel)
 
+    def keep_rows(self, on=True):
+        """Call before upload(): also keep a row-sorted copy of the matrix in HBM, from which batch
+        engines gather their rows (upload_rows) -- minibatch CAVI without host slicing or re-uploads."""
+        _lib.check(self._lib.schpf_keep_rows(self._h, int(bool(on))))
+
+    def upload_rows(self, source, rows):
+        """This engine's matrix := rows `rows` (in that order) of `source`'s matrix (a DeviceCAVI on the
+        same device that was told to keep_rows()); len(rows) must be this engine's ncells."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        _lib.check(self._lib.schpf_upload_rows(self._h, source._h, _p(rows), int(rows.shape[0])))
+        self.nnz = self.upload_info()["nnz"]
+
     def upload_info(self):
         """{'nnz', 'rounded' (values rounded to float32), 'zeros' (explicitly stored), 'packed'}."""
         info = (ctypes.c_int64 * 4)()

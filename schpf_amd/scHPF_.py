@@ -459,11 +459,14 @@ class scHPF(BaseEstimator):
         """Minibatch CAVI (scHPF_.py:643-650, 688-704): each iteration updates a batch of cells
         first (theta.rate from the current beta), then the genes from that batch alone.
 
-        One engine of `batchsize` cells lives for the whole fit: eta/beta and their tables stay on
-        the device from iteration to iteration; per iteration only the batch's rows are sent (the
-        plans of a batch are rebuilt by device passes, work proportional to the batch) together
-        with the batch's xi/theta rows, which come back after the step.  The default loss (all
-        cells) is evaluated by a second engine that holds the whole matrix for the whole fit."""
+        The matrix goes to the device ONCE: a whole-matrix engine keeps it as plans (for the default
+        all-cells loss) and as a row-sorted copy (DeviceCAVI.keep_rows); per iteration the batch engine
+        -- `batchsize` cells, alive for the whole fit, eta/beta and their tables resident -- gathers the
+        batch's rows from that copy and plans them by device passes (upload_rows: work proportional to
+        the batch, nothing over PCIe but the row numbers), where the reference re-slices X on the host
+        (X[batch_ix], :643-650).  The batch's xi/theta rows travel with it (a few MB) and come back
+        after the step.  Only iteration 0 of a reinitialised fit slices on the host: its random
+        responsibilities are drawn per nonzero of X_batch in the reference's order."""
         from .util import minibatch_ix_generator
         nfactors = self.nfactors
         a, ap, c, cp = self.a, self.ap, self.c, self.cp
@@ -471,15 +474,22 @@ class scHPF(BaseEstimator):
         batches = minibatch_ix_generator(X.shape[0], batchsize)
         dtype = np.dtype(self.dtype)
         default_loss = loss_function is None
+        # the reference batches X.tocsr(), which sums duplicate entries, and scores X as given
+        duplicates = Xcsr.nnz != X.data.shape[0]
         from contextlib import ExitStack
         with ExitStack() as stack:
             eng = stack.enter_context(DeviceCAVI(batchsize, X.shape[1], nfactors, dtype=dtype, device=device))
             eng.set_hypers(a, c, bp, dp)
             eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
             eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
+            source = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
+            source.keep_rows()
+            source.upload(Xcsr.tocoo() if duplicates else X)
+            whole = source
             if default_loss:
-                whole = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
-                whole.upload(X)
+                if duplicates:
+                    whole = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
+                    whole.upload(X)
                 whole.set_hypers(a, c, bp, dp)
 
             def gene_side():      # eta.vi_shape is a constant of the model (:618); its rate and beta live on the device
@@ -489,13 +499,15 @@ class scHPF(BaseEstimator):
 
             for t in range(max_iter):
                 batch_ix = next(batches)
-                X_batch = Xcsr[batch_ix, :].tocoo()
-                eng.upload(X_batch)
-                eng.set_gamma("xi", xi.vi_shape[batch_ix], xi.vi_rate[batch_ix])
-                eng.set_gamma("theta", theta.vi_shape[batch_ix], theta.vi_rate[batch_ix])
                 if t == 0 and reinit:
+                    X_batch = Xcsr[batch_ix, :].tocoo()
+                    eng.upload(X_batch)
                     random_phi = np.random.dirichlet(np.ones(nfactors), X_batch.data.shape[0])
                     eng.init_phi_host(X_batch.data[:, None] * random_phi)
+                else:
+                    eng.upload_rows(source, batch_ix)
+                eng.set_gamma("xi", xi.vi_shape[batch_ix], xi.vi_rate[batch_ix])
+                eng.set_gamma("theta", theta.vi_shape[batch_ix], theta.vi_rate[batch_ix])
                 eng.step(freeze_genes=freeze_genes, simultaneous=beta_theta_simultaneous,
                          cells_first=not beta_theta_simultaneous)
                 ths, thr = eng.get_gamma("theta")

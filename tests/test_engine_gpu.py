@@ -616,6 +616,56 @@ def test_sharded_protocol_two_engines_on_one_gpu(amd, oracle, flags):
         e.close()
 
 
+@only_plans("tile", "half")
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("coo_order", ["canonical", "shuffled"])
+def test_rows_gathered_on_the_device_equal_a_host_slice(amd, oracle, plan_kind, dtype, coo_order):
+    """Minibatch rows without re-uploads (schpf_keep_rows / schpf_upload_rows): a batch engine whose rows
+    were gathered from the source engine's resident copy iterates BITWISE like one that was handed
+    X.tocsr()[rows].tocoo() by the host (the reference's own slicing, scHPF_.py:643-650) -- rows in any
+    order, repeated batches, empty rows included; and the batch engine refuses to score itself."""
+    from scipy.sparse import coo_matrix
+    X = synthetic_counts(3000, 1500, 0.04, seed=21)
+    X.data[::11] += 70000 if np.dtype(dtype) == np.float64 else 0      # f64 case: unpacked 16-byte entries
+    if coo_order == "shuffled":
+        perm = np.random.RandomState(1).permutation(X.nnz)
+        X = coo_matrix((X.data[perm], (X.row[perm], X.col[perm])), shape=X.shape)
+    K, a, c, nb = 12, 0.3, 0.3, 700
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=9)
+    Xcsr = X.tocsr()
+    Xcsr.sort_indices()
+    rng = np.random.RandomState(5)
+    with amd.DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype) as source, \
+            amd.DeviceCAVI(nb, X.shape[1], K, dtype=dtype) as dev, amd.DeviceCAVI(nb, X.shape[1], K, dtype=dtype) as host:
+        source.keep_rows()
+        source.upload(X)
+        for eng in (dev, host):
+            eng.set_hypers(a, c, bp, dp)
+            eng.set_gamma("eta", st.eta_shape, st.eta_rate)
+            eng.set_gamma("beta", st.beta_shape, st.beta_rate)
+        for it in range(3):
+            rows = rng.permutation(X.shape[0])[:nb].astype(np.int32)
+            dev.upload_rows(source, rows)
+            host.upload(Xcsr[rows, :].tocoo())
+            assert dev.nnz == host.nnz
+            for eng in (dev, host):
+                eng.set_gamma("xi", st.xi_shape[rows], st.xi_rate[rows])
+                eng.set_gamma("theta", st.theta_shape[rows], st.theta_rate[rows])
+                eng.step(cells_first=True)
+                eng.step()
+            for name in ("xi", "theta", "eta", "beta"):
+                (s0, r0), (s1, r1) = dev.get_gamma(name), host.get_gamma(name)
+                assert np.array_equal(s0, s1) and np.array_equal(r0, r1), name
+        with pytest.raises(Exception, match="source"):
+            dev.mean_negative_pois_llh()
+        with pytest.raises(ValueError):
+            dev.upload_rows(source, np.arange(nb - 1, dtype=np.int32))
+        with pytest.raises(ValueError):
+            dev.upload_rows(source, np.full(nb, X.shape[0], dtype=np.int32))
+        with pytest.raises(Exception, match="keeps no rows"):
+            dev.upload_rows(host, np.arange(nb, dtype=np.int32))
+
+
 def test_minibatch_fit_reproduces_reference_trace(amd):
     """batchsize=32 (reference scHPF_.py:626-650, 688-704): cell block first, genes from the
     batch; same shuffle, same Dirichlet draws, same losses and parameters."""
@@ -891,8 +941,7 @@ def test_fit_over_devices_reproduces_reference_trace(amd, monkeypatch, fname, dt
 
 def load_shard_engine(amd, X, K, dtype, st, a, c, bp, dp):
     """load_engine for a rank of a sharded fit: hint_sharded() before the upload, as ThreadedShards and
-    bench.py do -- the plans' launch order then lists the gene-side tasks first and schpf_steps_sharded
-    runs the single-launch iteration (kernels.h ShardSync)."""
+    bench.py do -- the task ranges are then chosen for two sweep launches per iteration."""
     eng = amd.DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype)
     eng.hint_sharded()
     eng.upload(X)
@@ -909,8 +958,8 @@ def test_library_rccl_one_rank_equals_plain_steps(amd, oracle, hinted):
     """The collective inside the library (schpf_comm_init / schpf_steps_sharded / schpf_loss_terms_all,
     RCCL bound at run time to the copy already in the process): a one-rank communicator on the GPU
     box.  The sharded iteration -- two sweep launches, packing, all-reduce on the communicator's
-    stream ordered by events, update from the exchange buffer; or, hinted, ONE sweep launch that packs
-    the gene side's sums itself and releases the all-reduce through a device flag -- must equal the oracle."""
+    stream ordered by events, update from the exchange buffer -- must equal the oracle, with the plans
+    of a plain engine and with those of a hinted rank."""
     from schpf_amd.sharded import NativeShard
     X = synthetic_counts(700, 500, 0.06, seed=17)
     K, a, c = 20, 0.3, 0.3
@@ -931,43 +980,33 @@ def test_library_rccl_one_rank_equals_plain_steps(amd, oracle, hinted):
 @only_plans("tile", "half")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("graph", ["0", "1"])
-def test_single_launch_sharded_iteration_matches_oracle_and_two_launch_path(amd, oracle, plan_kind, dtype, graph,
-                                                                             monkeypatch):
-    """The single-launch iteration of a row shard (gene-side tasks first, their sums packed by the last
-    workgroups to finish one, the all-reduce gated by a device flag on the communicator's stream) at a size
-    with several rounds of tasks per compute unit, eager and as a captured hipGraph, through mode switches
-    (simultaneous / frozen genes / plain single-GPU steps in between, which read the sums the sweep no longer
-    keeps up to date): equal to the oracle, and BITWISE equal to the two-launch path -- the packing inside
-    the sweep does combine_strided_kernel's arithmetic in its order."""
+def test_sharded_stretches_with_mode_switches_match_oracle(amd, oracle, plan_kind, dtype, graph, monkeypatch):
+    """The library-driven sharded iteration (schpf_steps_sharded, one-rank communicator) at a size with
+    several rounds of tasks per compute unit, eager and with the stretch captured as a hipGraph (both
+    streams, the events between them and the RCCL call), through mode switches: simultaneous, frozen
+    genes, plain single-GPU steps in between, odd and even stretch lengths (the per-parity graph cache)."""
     from schpf_amd.sharded import NativeShard
     monkeypatch.setenv("SCHPF_GRAPH_SHARDED", graph)
-    X = synthetic_counts(20000, 8000, 0.015, seed=12)        # > 256 tasks per side: the counter is really used
+    X = synthetic_counts(20000, 8000, 0.015, seed=12)
     K, a, c = 20, 0.3, 0.3
     f32 = np.dtype(dtype) == np.float32
-    bp, dp, st = random_state(oracle, X, K, dtype, seed=4)
-    seq = [(1, {}), (4, {}), (4, {}), (1, {"simultaneous": True}), (2, {"freeze_genes": True}), (3, {})]
-    states = {}
-    for single in ("1", "0"):
-        monkeypatch.setenv("SCHPF_SHARD_SINGLE", single)
-        ref = st.copy()
-        with load_shard_engine(amd, X, K, dtype, ref, a, c, bp, dp) as eng:
-            shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)
-            done = 0
-            for n, flags in seq:
-                shard.steps(n, **flags)
-                for _ in range(n):
-                    oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp, **flags)
-                done += n
-                compare_state(eng, ref, rtol=(2e-5 * done) if f32 else 1e-10)
-            eng.step()                                        # a plain step: needs s_theta brought up to date
+    bp, dp, ref = random_state(oracle, X, K, dtype, seed=4)
+    seq = [(1, {}), (4, {}), (4, {}), (5, {}), (4, {}), (1, {"simultaneous": True}), (2, {"freeze_genes": True}), (3, {})]
+    with load_shard_engine(amd, X, K, dtype, ref, a, c, bp, dp) as eng:
+        shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)
+        done = 0
+        for n, flags in seq:
+            shard.steps(n, **flags)
+            for _ in range(n):
+                oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp, **flags)
+            done += n
+            compare_state(eng, ref, rtol=(2e-5 * done) if f32 else 1e-10)
+        eng.step()
+        oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp)
+        shard.steps(2)
+        for _ in range(2):
             oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp)
-            shard.steps(2)
-            for _ in range(2):
-                oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp)
-            compare_state(eng, ref, rtol=(2e-5 * (done + 3)) if f32 else 1e-10)
-            states[single] = [eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")]
-    for (s1, r1), (s0, r0) in zip(states["1"], states["0"]):
-        assert np.array_equal(s1, s0) and np.array_equal(r1, r0)
+        compare_state(eng, ref, rtol=(2e-5 * (done + 3)) if f32 else 1e-10)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 cfg=${CFG:-c3}
 for i in 1 2; do
   for tag in "$@"; do
-    SCHPF_LIB_PATH=$R/schpf_amd/libschpf_hip_dev_$tag.so python $R/tools/explore.py $cfg ${SETTINGS:-"dtype=f64" "dtype=f32"} 2>&1 | grep setting | python -c "
+    SCHPF_LIB_PATH=$R/schpf_amd/libschpf_hip_dev_$tag.so python $R/tools/explore.py $cfg ${SETTINGS:-dtype=f64 dtype=f32} 2>&1 | grep setting | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l)
