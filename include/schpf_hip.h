@@ -215,7 +215,8 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]);
 
 /* Facts about the uploaded matrix: info = {nnz, values that were rounded to float32, explicitly
- * stored zeros, 1 if the packed 8-byte entry format is in use}. */
+ * stored zeros, bit 0: the packed 8-byte entry format is in use | bit 1: a row-sorted copy is resident
+ * (schpf_keep_rows took effect: device-built tile plans)}. */
 int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]);
 
 /* Row sums (per cell) and column sums (per gene) of a host COO matrix: the inputs of the empirical

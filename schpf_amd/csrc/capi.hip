@@ -1012,6 +1012,7 @@ template <typename T> struct Engine final : schpf_ctx {
         chunk &= ~1;
         use_tile = want_tile;
         cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
+        rows_ptr.release(); rows_col.release(); rows_val.release();   // kept again below, by the device-plan path only
         int64_t n_out;
         if (use_tile) {
             if (device_plans) build_tiles_device(row, col, v.data(), packed_ok, early);
@@ -1434,7 +1435,7 @@ template <typename T> struct Engine final : schpf_ctx {
     void upload_info(int64_t info[4]) override
     {
         info[0] = nnz; info[1] = n_rounded; info[2] = n_zero;
-        info[3] = use_tile ? (tcell.packed ? 1 : 0) : 0;
+        info[3] = (use_tile ? (tcell.packed ? 1 : 0) : 0) | (rows_ptr.p ? 2 : 0);   // bit 1: a row-sorted copy is kept
     }
 
     void plan_info(int64_t info[16]) override

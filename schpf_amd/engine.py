@@ -120,10 +120,13 @@ class DeviceCAVI(object):
         self.nnz = self.upload_info()["nnz"]
 
     def upload_info(self):
-        """{'nnz', 'rounded' (values rounded to float32), 'zeros' (explicitly stored), 'packed'}."""
+        """{'nnz', 'rounded' (values rounded to float32), 'zeros' (explicitly stored), 'packed', 'rows'
+        (a row-sorted copy is resident: keep_rows() took effect -- device-built tile plans only)}."""
         info = (ctypes.c_int64 * 4)()
         _lib.check(self._lib.schpf_upload_info(self._h, info))
-        return dict(zip(("nnz", "rounded", "zeros", "packed"), [int(v) for v in info]))
+        out = dict(zip(("nnz", "rounded", "zeros"), [int(v) for v in info[:3]]))
+        out["packed"], out["rows"] = int(info[3]) & 1, bool(int(info[3]) & 2)
+        return out
 
     def set_hypers(self, a, c, bp, dp):
         _lib.check(self._lib.schpf_set_hypers(self._h, float(a), float(c), float(bp), float(dp)))

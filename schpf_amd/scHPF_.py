@@ -485,6 +485,7 @@ class scHPF(BaseEstimator):
             source = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
             source.keep_rows()
             source.upload(Xcsr.tocoo() if duplicates else X)
+            resident = source.upload_info()["rows"]     # False for host-built / gather plans: slice on the host then
             whole = source
             if default_loss:
                 if duplicates:
@@ -499,11 +500,12 @@ class scHPF(BaseEstimator):
 
             for t in range(max_iter):
                 batch_ix = next(batches)
-                if t == 0 and reinit:
+                if (t == 0 and reinit) or not resident:
                     X_batch = Xcsr[batch_ix, :].tocoo()
                     eng.upload(X_batch)
-                    random_phi = np.random.dirichlet(np.ones(nfactors), X_batch.data.shape[0])
-                    eng.init_phi_host(X_batch.data[:, None] * random_phi)
+                    if t == 0 and reinit:
+                        random_phi = np.random.dirichlet(np.ones(nfactors), X_batch.data.shape[0])
+                        eng.init_phi_host(X_batch.data[:, None] * random_phi)
                 else:
                     eng.upload_rows(source, batch_ix)
                 eng.set_gamma("xi", xi.vi_shape[batch_ix], xi.vi_rate[batch_ix])

@@ -639,6 +639,7 @@ def test_rows_gathered_on_the_device_equal_a_host_slice(amd, oracle, plan_kind, 
             amd.DeviceCAVI(nb, X.shape[1], K, dtype=dtype) as dev, amd.DeviceCAVI(nb, X.shape[1], K, dtype=dtype) as host:
         source.keep_rows()
         source.upload(X)
+        assert source.upload_info()["rows"]
         for eng in (dev, host):
             eng.set_hypers(a, c, bp, dp)
             eng.set_gamma("eta", st.eta_shape, st.eta_rate)
