@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/pmc1_$tag
 rm -rf $out
-timeout 600 rocprofv3 --pmc $ctr -d $out -o pmc -- python $R/bench.py "$@" --no-cpu-baseline --no-converge > $out.log 2>&1
+timeout 600 rocprofv3 --pmc $ctr -d $out -o pmc -- python $R/bench.py "$@" --no-cpu-baseline --no-converge --no-traffic > $out.log 2>&1
 python $R/tools/rocpd_summary.py $(find $out -name "*.db" | head -1) | grep -E "tile_sweep_dual|counter" > $R/gpurun_out/pmc1_$tag.txt
 rm -rf $out
 cat $R/gpurun_out/pmc1_$tag.txt

@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   out=$R/gpurun_out/pmc_${tag}_$name
   rm -rf $out
-  timeout 600 rocprofv3 --pmc $grp -d $out -o pmc -- python $R/bench.py "$@" --no-cpu-baseline --no-converge > $out.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp -d $out -o pmc -- python $R/bench.py "$@" --no-cpu-baseline --no-converge --no-traffic > $out.log 2>&1
   db=$(find $out -name "*.db" | head -1)
   python $R/tools/rocpd_summary.py $db | grep -E "tile_sweep|counter" > $R/gpurun_out/pmc_${tag}_$name.txt
   rm -rf $out

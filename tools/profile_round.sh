@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-converge"
+BENCH="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-converge --no-traffic"
 rm -rf $O/${tag}_stats
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/${tag}_stats -o c3f64 -- $BENCH > $O/${tag}_bench_under_rocprof_c3_f64.json 2> $O/${tag}_stats.log
 python $R/tools/rocpd_summary.py $(find $O/${tag}_stats -name "*.db" | head -1) > $O/${tag}_kernel_stats_c3_f64.txt 2>&1
@@ -21,10 +21,10 @@ rm -rf $O/${tag}_stats
 cd $R
 python bench.py > $O/${tag}_bench_c3_f64.json 2> $O/${tag}_bench_c3_f64.err
 python bench.py --dtype f32 --no-cpu-baseline > $O/${tag}_bench_c3_f32.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c2 --no-cpu-baseline --no-converge > $O/${tag}_bench_c2_f64.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c5-shard --no-cpu-baseline --no-converge --steps 30 --warmup 5 > $O/${tag}_bench_c5shard_f64.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --force-sharded --no-cpu-baseline --no-converge > $O/${tag}_bench_c3_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c4-shard --force-sharded --no-cpu-baseline --no-converge > $O/${tag}_bench_c4shard_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c2 --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c2_f64.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c5-shard --no-cpu-baseline --no-converge --no-traffic --steps 30 --warmup 5 > $O/${tag}_bench_c5shard_f64.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c3_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c4-shard --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
 for f in $O/${tag}_bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:
