@@ -436,7 +436,7 @@ def live_traffic(X, K, dtype_name, steps=8):
             cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", path, "--pmc-k", str(K), "--dtype", dtype_name, "--steps", str(steps)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
             dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not dbs:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-200:])
@@ -684,7 +684,7 @@ def main():
         "iterations_per_s_with_loss_every_10": 10.0 / (10 * ms_per_step * 1e-3 + loss_ms * 1e-3),
         "upload_and_plan_s": upload_s,
     }
-    if rank == 0 and world == 1 and not args.no_traffic:
+    if rank == 0 and world == 1 and not sharded and not args.no_traffic:
         eng.close()
         live, how = live_traffic(X, K, args.dtype)
         if live is not None:

@@ -96,7 +96,7 @@ def test_bench_line_over_ranks(world):
     finite rate and a loss that moved (world = 1: the same sharded driver with one rank)."""
     need_gpus(world)
     r = _torchrun(world, ["bench.py", "--gpus", str(world), "--config", "c2", "--steps", "20", "--warmup", "5",
-                          "--no-cpu-baseline", "--no-converge"] + (["--force-sharded"] if world == 1 else []))
+                          "--no-cpu-baseline", "--no-converge", "--no-traffic"] + (["--force-sharded"] if world == 1 else []))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == world and line["steps"] == 20

@@ -25,6 +25,11 @@ python bench.py --config c2 --no-cpu-baseline --no-converge --no-traffic > $O/${
 python bench.py --config c5-shard --no-cpu-baseline --no-converge --no-traffic --steps 30 --warmup 5 > $O/${tag}_bench_c5shard_f64.json 2>> $O/${tag}_bench_c3_f64.err
 python bench.py --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c3_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
 python bench.py --config c4-shard --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c4-shard4 --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard4_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c4-shard2 --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard2_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c5-shard --dtype f32 --no-cpu-baseline --no-converge --no-traffic --steps 30 --warmup 5 > $O/${tag}_bench_c5shard_f32.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c2 --dtype f32 --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c2_f32.json 2>> $O/${tag}_bench_c3_f64.err
+python bench.py --config c5 --no-cpu-baseline --no-converge --no-traffic --steps 20 --warmup 3 > $O/${tag}_bench_c5_whole_f64.json 2>> $O/${tag}_bench_c3_f64.err
 for f in $O/${tag}_bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:
