@@ -64,26 +64,6 @@ template <typename T> __device__ __forceinline__ double sum_strided(const T *__r
     return (s0 + s1) + (s2 + s3);
 }
 
-// Column sums of per-block partials [nblocks, K] in ONE fixed order that does not depend on who computes them
-// (colsum_reduce_kernel today; a sweep epilogue could take the sums over): factor k is summed by
-// VJ = max(1, 1024 / K) virtual lanes -- lane j takes the blocks j, j + VJ, ... through eight interleaved
-// accumulators -- and the lanes' values are then added in lane order.
-__host__ __device__ inline int colsum_lanes(int K) { return K >= 1024 ? 1 : 1024 / K; }
-__device__ __forceinline__ double colsum_lane(const double *__restrict__ part, int nblocks, int K, int k, int j, int VJ)
-{
-    double q[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    int b = j;
-    for (; b + 7 * VJ < nblocks; b += 8 * VJ) {      // eight loads in flight: the partials sit in L2
-        double v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = part[(size_t)(b + i * VJ) * K + k];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] += v[i];
-    }
-    for (; b < nblocks; b += VJ) q[0] += part[(size_t)b * K + k];
-    return ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-}
-
 template <typename T> struct UpdateArgs {
     int n, K, KP, rows_per_block;
     const T *partials;          // SRC_PARTIALS: [n_chunks, KP]

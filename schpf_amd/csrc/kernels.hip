@@ -152,20 +152,31 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
     if (t < K) a.colsum_part[(size_t)blockIdx.x * K + t] = sC[t];
 }
 
-// colsum_part [nblocks, K] -> out[K] (double), in the fixed order of kernels.h colsum_lane.  One workgroup per
-// factor: every virtual lane has its loads in flight at once, then lane 0 adds the lanes' values in turn.
+// colsum_part [nblocks, K] -> out[K] (double), fixed order.  One workgroup per factor: every
+// thread has its (few) loads in flight at once, then a fixed-shape tree in LDS -- one memory
+// round trip instead of a serial walk over the blocks.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double *__restrict__ part, int nblocks,
                                                              int K, double *__restrict__ out,
                                                              void *mirror, int mirror_is_f32)
 {
-    __shared__ double red[1024];
+    __shared__ double red[256];
     const int t = threadIdx.x, k = blockIdx.x;
-    const int VJ = colsum_lanes(K);
-    for (int j = t; j < VJ; j += 256) red[j] = colsum_lane(part, nblocks, K, k, j, VJ);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = t;
+    for (; b + 768 < nblocks; b += 1024) {
+        const double v0 = part[(size_t)b * K + k], v1 = part[(size_t)(b + 256) * K + k];
+        const double v2 = part[(size_t)(b + 512) * K + k], v3 = part[(size_t)(b + 768) * K + k];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < nblocks; b += 256) s0 += part[(size_t)b * K + k];
+    red[t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (t < m) red[t] += red[t + m];
+        __syncthreads();
+    }
     if (t == 0) {
-        double tot = 0.0;
-        for (int j = 0; j < VJ; ++j) tot += red[j];
+        const double tot = red[0];
         out[k] = tot;
         if (mirror) {
             if (mirror_is_f32) ((float *)mirror)[k] = (float)tot;
