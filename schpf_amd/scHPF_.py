@@ -374,6 +374,9 @@ class scHPF(BaseEstimator):
         monitor = _LossMonitor(self.epsilon, self.better_than_n_ago, min_iter, loss_smoothing)
 
         if batched:
+            if devices is not None and len(devices) > 1:
+                raise ValueError("minibatch fits (batchsize=...) run on one device: a batch is a row subset that one "
+                                 "GPU holds whole; give one device or drop batchsize")
             return self._fit_minibatch(X, bp, dp, xi, eta, theta, beta, monitor, freeze_genes, reinit,
                                        loss_function, max_iter, check_freq, checkstep_function, verbose,
                                        batchsize, beta_theta_simultaneous, device)

@@ -171,6 +171,14 @@ def test_project_argument_check(model, data):
         model.project(data, recalc_bp=True, replace=True)
 
 
+def test_minibatch_over_several_devices_is_refused(data):
+    """A batch is a row subset one GPU holds whole: batchsize with devices=[0, 1] is an argument error, raised
+    before anything touches a device."""
+    from schpf import scHPF
+    with pytest.raises(ValueError, match="one device"):
+        scHPF(4, verbose=False).fit(data, batchsize=32, devices=[0, 1])
+
+
 def test_minibatch_generator_cycles_and_wraps():
     from schpf.util import minibatch_ix_generator
     np.random.seed(5)
