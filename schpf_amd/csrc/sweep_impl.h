@@ -578,7 +578,6 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     double llh = 0.0;
     LlhAccumulator lacc;   // MODE_LLH
     bool any_bad = false;
-    const T tiny = Vec16<T>::tiny();
     // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
     constexpr bool PAIR = KL * (int)sizeof(T) <= (MAXT <= 512 ? 192 : 96);
     constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
