@@ -570,13 +570,6 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     const int g = wv * GPW + grp;
     const int major = a.block_rows[(size_t)blk * gpb + g];
     const bool live = major >= 0;
-#if SCHPF_ABLATE == 11      /* static issue priority for the second-dispatched half of the workgroup's waves */
-    if (wv >= a.wpb / 2) __builtin_amdgcn_s_setprio(1);
-#elif SCHPF_ABLATE == 12    /* ... for every other wave */
-    if (wv & 1) __builtin_amdgcn_s_setprio(1);
-#elif SCHPF_ABLATE == 13    /* ... for one wave of the four that share a SIMD */
-    if ((wv >> 2) == 0) __builtin_amdgcn_s_setprio(2);
-#endif
 
     T tm[KL], acc[KL];
 #pragma unroll
