@@ -10,6 +10,9 @@ runs over real RCCL ranks:
   * two / four / eight PROCESSES under torch.distributed.run, NativeShard, against the oracle at
     BASELINE C2 size (tests/_multigpu_worker.py), eager and with the stretch captured as a hipGraph;
   * `bench.py --gpus N` as a smoke of the driver's own launch line.
+
+One two-process case needs no second GPU and runs everywhere: both ranks on cuda:0, the all-reduce of the
+device-resident exchange buffer carried by gloo (tests/_gloo_gpu_worker.py).
 """
 import json
 import os
@@ -88,6 +91,16 @@ def test_native_shards_under_torchrun_match_oracle(world, dtype, graph):
     r = _torchrun(world, ["tests/_multigpu_worker.py", "--dtype", dtype, "--graph", str(graph)])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("parity ok") == world, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_two_processes_share_one_gpu_with_a_gloo_exchange(dtype):
+    """Runs on EVERY box: two processes, each a rank with its own DeviceCAVI on cuda:0, the product's packing
+    and update-from-exchange kernels and ShardedCAVI, the all-reduce of the device-resident exchange buffer
+    carried by gloo (RCCL refuses two ranks on one device) -- against the oracle (tests/_gloo_gpu_worker.py)."""
+    r = _torchrun(2, ["tests/_gloo_gpu_worker.py", "--dtype", dtype])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("parity ok") == 2, r.stdout[-2000:]
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
