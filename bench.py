@@ -505,6 +505,12 @@ def main():
                          "static record is attached, if it is of this plan)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--pmc-k", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of sharded runs (nccl = RCCL; gloo only with --comm torch: the "
+                         "exchange buffer is then staged through the host -- a plumbing check, not a measurement)")
+    ap.add_argument("--same-gpu", action="store_true",
+                    help="every rank on device 0 (one-GPU boxes: exercises the N > 1 code path of this script with "
+                         "--comm torch --backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the wall-clock-to-convergence fits (second half of BASELINE.json's metric)")
     args = ap.parse_args()
@@ -525,13 +531,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
                              "--gpus %d ..." % (args.gpus, args.gpus))
+    if args.same_gpu:
+        local_rank = 0
+    if args.backend == "gloo" and args.comm != "torch":
+        raise SystemExit("--backend gloo needs --comm torch (the library's collective is RCCL)")
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from schpf_amd import DeviceCAVI
     from schpf_amd.sharded import ShardedCAVI, exchange_tensor_of

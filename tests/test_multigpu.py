@@ -103,6 +103,19 @@ def test_two_processes_share_one_gpu_with_a_gloo_exchange(dtype):
     assert r.stdout.count("parity ok") == 2, r.stdout[-2000:]
 
 
+def test_bench_line_of_two_ranks_on_one_gpu():
+    """bench.py's N = 2 code path on a one-GPU box: two ranks on device 0, torch-driven exchange over gloo --
+    row blocks per rank, the rank-summed nnz, the MAX-over-ranks timing and rank 0's JSON line (the numbers
+    are not a measurement: gloo stages the exchange buffer through the host)."""
+    r = _torchrun(2, ["bench.py", "--gpus", "2", "--config", "c2", "--steps", "10", "--warmup", "3", "--comm", "torch",
+                      "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--no-converge", "--no-traffic"])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "strong"
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
+
+
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_bench_line_over_ranks(world):
     """The driver's launch line for N > 1 at C2 size: one JSON line from rank 0 with n_gpus = N, a
