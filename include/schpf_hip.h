@@ -238,7 +238,9 @@ int schpf_debug_plan_expand(int64_t nnz, const int32_t *major, const int32_t *mi
 
 /* Same for the tile plan (LDS-staged sweep): per stored nonzero the major/minor/val, the partial
  * row (task * groups_per_block + group) it accumulates into and its task; pfirst/pcount[n_major];
- * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task}.
+ * stats = {n_tasks, n_blocks, n_windows, pstride, stored entry slots, windows_per_task, LDS passes that read a
+ * row, extra LDS cycles of those passes under the bank model of plan.cpp (rows of one class are serialised)};
+ * $SCHPF_BANK_ORDER picks the order inside a segment (plan.h TileShape::bank_order).
  * ring <= 1: window schedule with win_rows rows per window; ring <= -2: the half-window schedule with
  * -ring slots of slot_bytes (a multiple of 16; table rows are 160 bytes here) -- the hook then also
  * checks that every entry of an epoch points into a slot readable in that epoch. */
@@ -246,7 +248,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                             int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
                             int target_tasks, int ring, int slot_bytes, int32_t *out_major,
                             int32_t *out_minor, float *out_val, int32_t *out_prow, int32_t *out_task,
-                            int32_t *out_pfirst, int32_t *out_pcount, int64_t stats[6]);
+                            int32_t *out_pfirst, int32_t *out_pcount, int64_t stats[8]);
 
 /* Measurement hook: the first n doubles of the engine's per-wave output buffer (the loss sweep's partial
  * sums; development builds with -DSCHPF_ABLATE=9 leave each persistent workgroup's finishing time there,

@@ -801,7 +801,7 @@ template <typename T> struct Engine final : schpf_ctx {
         sh.lpc = LPC;
         sh.waves_per_block = wpb;
         sh.row_slots = (int)(row_bytes / 16);
-        sh.bank_order = env_int("SCHPF_BANK_ORDER", 1) != 0;
+        sh.bank_order = env_int("SCHPF_BANK_ORDER", 2);   // 0 minor order, 1 per row, 2 jointly per LDS pass (plan.h)
         sh.allow_packed = env_int("SCHPF_PACK", 1) != 0;
         sh.win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
         // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
@@ -1865,17 +1865,25 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                             int n_major, int n_minor, int lpc, int waves_per_block, int win_rows,
                             int target_tasks, int ring, int slot_bytes, int32_t *out_major, int32_t *out_minor,
                             float *out_val, int32_t *out_prow, int32_t *out_task, int32_t *out_pfirst,
-                            int32_t *out_pcount, int64_t stats[6])
+                            int32_t *out_pcount, int64_t stats[8])
 {
     return guarded([&] {
         schpf::TilePlanHost P;
         schpf::TileShape sh;
         sh.lpc = lpc; sh.waves_per_block = waves_per_block; sh.win_rows = win_rows; sh.target_tasks = target_tasks;
-        sh.row_slots = 10;   // 160-byte table rows
+        sh.row_slots = env_int("SCHPF_DEBUG_ROW_SLOTS", 10);   // 160-byte table rows
         sh.ring = ring < 0 ? -ring : ring; sh.sync_stage = sh.ring > 1 ? 1 : 0; sh.slot_bytes = slot_bytes;
         sh.allow_packed = getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true;
+        sh.bank_order = env_int("SCHPF_BANK_ORDER", 2);
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, false, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
+        // the LDS model of plan.cpp::bank_order: the lane groups of a pass read one row each per half step; rows of
+        // one class (16-byte position mod 16, / lpc) are served one after the other
+        const std::vector<int> pass_of = schpf::tile_pass_of(lpc, gpw);
+        const int n_classes = std::max(1, 16 / std::max(1, lpc));
+        int lpc_shift = 0;
+        while ((1 << lpc_shift) < lpc) ++lpc_shift;
+        int64_t lds_reads = 0, lds_extra = 0;
         int64_t n = 0;
         for (int64_t t = 0; t < P.n_tasks; ++t) {
             const int b = P.task_block[(size_t)t];
@@ -1884,8 +1892,9 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                 for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                     const int steps = P.steps[((size_t)b * wpb + v) * W + w];
                     for (int p = 0; p < steps; ++p)
-                        for (int grp = 0; grp < gpw; ++grp)
-                            for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < 2; ++u) {
+                          int in_class[4][16] = {};
+                          for (int grp = 0; grp < gpw; ++grp) {
                                 float f;
                                 uint32_t off16;
                                 if (P.packed) {
@@ -1912,6 +1921,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                                     mn = w * P.win_rows + (int)(off16 / (uint32_t)P.row_slots);
                                 }
                                 if (f == 0.0f) continue;
+                                in_class[pass_of[(size_t)grp]][((off16 & 15u) >> lpc_shift) & (unsigned)(n_classes - 1)]++;
                                 if (schpf::tile_off16(P, mn) != off16) throw std::logic_error("tile plan: bad LDS position");
                                 if (n >= nnz) throw std::logic_error("tile plan stores more nonzeros than given");
                                 const int g = v * gpw + grp;
@@ -1921,7 +1931,13 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                                 out_prow[n] = (int32_t)(t * gpb + g);
                                 out_task[n] = (int32_t)t;
                                 ++n;
-                            }
+                          }
+                          for (int ps = 0; ps < 4; ++ps) {
+                              int worst = 0;
+                              for (int c = 0; c < 16; ++c) worst = std::max(worst, in_class[ps][c]);
+                              if (worst) { lds_reads++; lds_extra += worst - 1; }
+                          }
+                        }
                     off += schpf::tile_stored_steps(P, steps) * gpw;
                 }
             }
@@ -1930,6 +1946,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         for (int m = 0; m < n_major; ++m) { out_pfirst[m] = P.pfirst[(size_t)m]; out_pcount[m] = P.pcount[(size_t)m]; }
         stats[0] = P.n_tasks; stats[1] = P.n_blocks; stats[2] = P.n_windows; stats[3] = P.pstride;
         stats[4] = (int64_t)P.entries.size() / (P.packed ? 1 : 2); stats[5] = P.windows_per_task;
+        stats[6] = lds_reads; stats[7] = lds_extra;
     });
 }
 

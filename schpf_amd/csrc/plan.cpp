@@ -343,6 +343,67 @@ static void bank_order(const TilePlanHost &P, const int32_t *seg_minor, int n, b
     }
 }
 
+// Joint variant (TileShape::bank_order = 2).  The per-row rule above is blind to what the other
+// groups of the pass hold: a group whose wished class is empty falls back to its fullest class,
+// which another group of the pass may be reading at that very position (round-3 counters: 43 % of
+// the LDS cycles of the C3 sweep are such conflicts).  Here the groups of one wave and one window
+// are dealt together: at position t the groups of a pass pick in turn (the group of rank
+// (a + t) mod M is a-th, so nobody is always last), each the fullest class its pass has not read
+// yet at t (tile_joint_pick).  Segments longer than TILE_JOINT_MAX keep the per-row rule and
+// stand outside the bookkeeping (the device builder sorts a segment in LDS).
+// seg_minor[m] / seg_n[m]: the segment of lane group m of the wave; seq[m][t] as in bank_order.
+struct JointScratch {
+    std::vector<int32_t> pos, row_scratch;
+    std::vector<uint16_t> cnt, head;
+};
+static void bank_order_joint(const TilePlanHost &P, int gpw, const int32_t *const *seg_minor, const int *seg_n,
+                             const std::vector<int> &pass_of, const std::vector<int> &pass_rank,
+                             std::vector<std::vector<int32_t>> &seq, JointScratch &S)
+{
+    const int lpc = P.lpc;
+    const int C = std::max(1, 16 / std::max(1, lpc));
+    int lpc_shift = 0;
+    while ((1 << lpc_shift) < lpc) ++lpc_shift;
+    const unsigned cmask = (unsigned)C - 1u;
+    S.pos.resize((size_t)gpw * TILE_JOINT_MAX);
+    S.cnt.assign((size_t)gpw * 16, 0);
+    S.head.assign((size_t)gpw * 16, 0);
+    int lane_of[4][16];
+    for (int p = 0; p < 4; ++p)
+        for (int r = 0; r < 16; ++r) lane_of[p][r] = -1;
+    int max_n = 0;
+    for (int m = 0; m < gpw; ++m) {
+        const int n = seg_n[m];
+        seq[(size_t)m].resize((size_t)n);
+        if (C > 1) lane_of[pass_of[(size_t)m]][pass_rank[(size_t)m]] = m;
+        if (n == 0) continue;
+        if (C == 1 || n > TILE_JOINT_MAX) {
+            bank_order(P, seg_minor[m], n, C > 1, pass_rank[(size_t)m], seq[(size_t)m], S.row_scratch);
+            continue;
+        }
+        max_n = std::max(max_n, n);
+        uint16_t *cnt = S.cnt.data() + (size_t)m * 16, *head = S.head.data() + (size_t)m * 16;
+        int32_t *pos = S.pos.data() + (size_t)m * TILE_JOINT_MAX;
+        for (int i = 0; i < n; ++i) cnt[((tile_off16(P, seg_minor[m][i]) & 15u) >> lpc_shift) & cmask]++;
+        int run = 0, cur[16];
+        for (int c = 0; c < C; ++c) { head[c] = (uint16_t)run; cur[c] = run; run += cnt[c]; }
+        for (int i = 0; i < n; ++i) pos[cur[((tile_off16(P, seg_minor[m][i]) & 15u) >> lpc_shift) & cmask]++] = i;
+    }
+    for (int t = 0; t < max_n; ++t)
+        for (int p = 0; p < 4; ++p) {
+            unsigned taken = 0;
+            for (int a = 0; a < C; ++a) {
+                const int m = lane_of[p][(a + t) & (int)cmask];
+                if (m < 0 || seg_n[m] > TILE_JOINT_MAX || t >= seg_n[m]) continue;
+                uint16_t *cnt = S.cnt.data() + (size_t)m * 16, *head = S.head.data() + (size_t)m * 16;
+                const int c = tile_joint_pick(cnt, 1, C, ((unsigned)pass_rank[(size_t)m] + (unsigned)t) & cmask, taken);
+                taken |= 1u << c;
+                seq[(size_t)m][(size_t)t] = S.pos[(size_t)m * TILE_JOINT_MAX + head[c]++];
+                cnt[c]--;
+            }
+        }
+}
+
 // ---- pieces of the tile plan that do not touch the nonzeros; shared by the host builder below
 // ---- and the device builder (plan_device.hip)
 
@@ -672,6 +733,14 @@ std::vector<int> tile_pass_rank(int lpc, int gpw)
     return pass_rank;
 }
 
+std::vector<int> tile_pass_of(int lpc, int gpw)
+{
+    std::vector<int> pass((size_t)gpw, 0);
+    static const int pass_of_quad[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};
+    for (int g2 = 0; g2 < gpw; ++g2) pass[(size_t)g2] = lpc > 16 ? 0 : pass_of_quad[g2 * lpc / 4];
+    return pass;
+}
+
 void tile_plan_report(const TilePlanHost &P)
 {
     // where the stored slots go: nonzeros / sliced-ELL padding inside a wave / waiting at the
@@ -851,7 +920,63 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     // segment the nonzeros may be taken in any order, so they are dealt to the steps in an
     // LDS-bank-aware order (see bank_order)
     const std::vector<int> pass_rank = tile_pass_rank(P.lpc, gpw);
-    parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
+    auto put = [&](int64_t win_first, int slot, int t, int64_t src) {
+        const uint32_t o16 = tile_off16(P, s_minor[(size_t)src]);
+        const size_t step_slot = (size_t)win_first + (size_t)(t >> 1) * gpw + slot;
+        if (packed) {
+            uint32_t *e = P.entries.data() + step_slot * 2;
+            const int sh = (t & 1) * 16;
+            e[0] = (e[0] & ~(0xFFFFu << sh)) | (o16 << sh);
+            e[1] |= (uint32_t)s_val[(size_t)src] << sh;
+        } else {
+            uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
+            e[0] = o16;
+            e[1] = f2u(s_val[(size_t)src]);
+        }
+    };
+    const bool joint = shape.bank_order == 2 && P.lpc <= 8;
+    if (joint) {
+        // wave by wave, window by window: the segments of the wave's lane groups are dealt together
+        const std::vector<int> pass_of = tile_pass_of(P.lpc, gpw);
+        parallel_for(P.n_blocks * wpb, nth, [&](int64_t bw0, int64_t bw1, int) {
+            JointScratch scratch;
+            std::vector<std::vector<int32_t>> seq((size_t)gpw);
+            std::vector<int64_t> cur((size_t)gpw), r0((size_t)gpw), end((size_t)gpw), seg_s((size_t)gpw);
+            std::vector<const int32_t *> seg_minor((size_t)gpw);
+            std::vector<int> seg_n((size_t)gpw);
+            for (int64_t bw = bw0; bw < bw1; ++bw) {
+                const int32_t *rows = P.block_rows.data() + (size_t)bw * gpw;   // gpb = wpb * gpw
+                for (int m = 0; m < gpw; ++m) {
+                    r0[(size_t)m] = cur[(size_t)m] = rows[m] < 0 ? 0 : mptr[rows[m]];
+                    end[(size_t)m] = rows[m] < 0 ? 0 : mptr[(size_t)rows[m] + 1];
+                }
+                int64_t off = wave_off[(size_t)bw];
+                for (int w = 0; w < W; ++w) {
+                    for (int m = 0; m < gpw; ++m) {
+                        int64_t s, e;
+                        if (ring) {
+                            const int32_t *st = starts.data() + ((size_t)bw * gpw + m) * ((size_t)W + 1);
+                            s = r0[(size_t)m] + (rows[m] < 0 ? 0 : st[w]);
+                            e = r0[(size_t)m] + (rows[m] < 0 ? 0 : st[w + 1]);
+                        } else {
+                            const int64_t bound = ((int64_t)w + 1) * win_rows;
+                            s = e = cur[(size_t)m];
+                            while (e < end[(size_t)m] && s_minor[(size_t)e] < bound) ++e;
+                            cur[(size_t)m] = e;
+                        }
+                        seg_s[(size_t)m] = s;
+                        seg_minor[(size_t)m] = s_minor.data() + s;
+                        seg_n[(size_t)m] = (int)(e - s);
+                    }
+                    bank_order_joint(P, gpw, seg_minor.data(), seg_n.data(), pass_of, pass_rank, seq, scratch);
+                    for (int m = 0; m < gpw; ++m)
+                        for (int t = 0; t < seg_n[(size_t)m]; ++t) put(off, m, t, seg_s[(size_t)m] + seq[(size_t)m][(size_t)t]);
+                    off += tile_stored_steps(P, P.steps[(size_t)bw * W + w]) * gpw;
+                }
+            }
+        });
+    }
+    else parallel_for(P.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
         std::vector<int64_t> win_off((size_t)W);
         std::vector<int32_t> seq;
         std::vector<int32_t> buckets;   // scratch of bank_order
@@ -880,22 +1005,8 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                     }
                     const int n = (int)(j - s);
                     seq.resize((size_t)n);
-                    bank_order(P, s_minor.data() + s, n, shape.bank_order, pass_rank[(size_t)slot], seq, buckets);
-                    for (int t = 0; t < n; ++t) {
-                        const int64_t src = s + seq[(size_t)t];
-                        const uint32_t o16 = tile_off16(P, s_minor[(size_t)src]);
-                        const size_t step_slot = (size_t)win_off[(size_t)w] + (size_t)(t >> 1) * gpw + slot;
-                        if (packed) {
-                            uint32_t *e = P.entries.data() + step_slot * 2;
-                            const int sh = (t & 1) * 16;
-                            e[0] = (e[0] & ~(0xFFFFu << sh)) | (o16 << sh);
-                            e[1] |= (uint32_t)s_val[(size_t)src] << sh;
-                        } else {
-                            uint32_t *e = P.entries.data() + step_slot * 4 + (size_t)(t & 1) * 2;
-                            e[0] = o16;
-                            e[1] = f2u(s_val[(size_t)src]);
-                        }
-                    }
+                    bank_order(P, s_minor.data() + s, n, shape.bank_order != 0, pass_rank[(size_t)slot], seq, buckets);
+                    for (int t = 0; t < n; ++t) put(win_off[(size_t)w], slot, t, s + seq[(size_t)t]);
                     if (ring) ++w;
                 }
             }

@@ -164,7 +164,8 @@ struct TilePlanHost {
 // Shape of a tile plan.  row_slots: 16-byte units per table row (KP * sizeof(T) / 16).
 // ring <= 1: window mode with win_rows rows per window.  ring >= 2 (with sync_stage = 1): half-window
 // schedule, slot_bytes per slot (win_rows is then derived: slot_bytes / row bytes).  bank_order: deal the nonzeros of a
-// segment to the steps in the LDS-bank-aware order (false = minor order).
+// segment to the steps in an LDS-bank-aware order -- 0: minor order; 1: every row on its own (plan.cpp bank_order);
+// 2: the rows that share an LDS pass jointly (plan.cpp bank_order_joint).
 struct TileShape {
     int lpc = 1, waves_per_block = 16, win_rows = 1, target_tasks = 0, row_slots = 1;
     int ring = 1, slot_bytes = 0;
@@ -172,7 +173,8 @@ struct TileShape {
     int slots = 0;          // workgroups of this orientation the GPU runs at once (0: unknown); see tile_plan_begin
     int ranges = 0;         // > 0: window ranges (tasks) per block, fixed by the caller (choose_task_ranges);
                             // target_tasks and the rounding by `slots` are then not consulted
-    bool bank_order = true, allow_packed = true;
+    int bank_order = 1;
+    bool allow_packed = true;
 };
 // How many window ranges (tasks per block) each orientation of a ONE-LAUNCH iteration should have.  The
 // merged launch runs its tasks longest first on `resident` workgroups that draw from one list, so the
@@ -241,6 +243,31 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
                      const int64_t *mptr);
 int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off);
 std::vector<int> tile_pass_rank(int lpc, int gpw);
+// the LDS pass (0..3) the lane group sits in, beside its rank inside that pass (tile_pass_rank)
+std::vector<int> tile_pass_of(int lpc, int gpw);
+// joint bank assignment (bank_order = 2): segments longer than this are dealt on their own (bank_order = 1 rule)
+constexpr int TILE_JOINT_MAX = 128;
+// The pick of one lane group at position t (both builders): counts per class cnt[0..n_classes), classes already
+// read by its pass in `taken`; the fullest class that is still free, ties to the class nearest (upwards, cyclic)
+// to the wish (rank + t) mod n_classes; when every class the group still has is taken, the fullest one.
+template <typename Count>
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int tile_joint_pick(const Count *cnt, int stride, int n_classes, unsigned wish, unsigned taken)
+{
+    unsigned best_free = 0, best_any = 0;
+    for (int c = 0; c < n_classes; ++c) {
+        const unsigned n = (unsigned)cnt[(size_t)c * stride];
+        const unsigned d = ((unsigned)c - wish) & (unsigned)(n_classes - 1);
+        const unsigned key = n ? (n << 4) | (15u - d) : 0u;
+        best_any = key > best_any ? key : best_any;
+        const unsigned fk = ((taken >> c) & 1u) ? 0u : key;
+        best_free = fk > best_free ? fk : best_free;
+    }
+    const unsigned key = best_free ? best_free : best_any;
+    return (int)((wish + (15u - (key & 15u))) & (unsigned)(n_classes - 1));
+}
 void tile_plan_report(const TilePlanHost &P);
 
 // the (major, minor) / (minor, major) order of a host COO (one threaded scan)

@@ -164,42 +164,14 @@ __global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const i
     if (owner) st[g.W] = done;
 }
 
-// fill, one thread per (row, window) segment: the segment's nonzeros are dealt to the steps in the
-// LDS-bank-aware order of plan.cpp::bank_order (wished class (rank + t) mod classes, else the
-// fullest class; inside a class in minor order).  win_off[(block, wave), window] = first step
-// slot of that window's entries.
-__global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restrict__ block_rows,
-                            const int64_t *__restrict__ mptr, const int32_t *__restrict__ s_minor,
-                            const float *__restrict__ s_val, const int64_t *__restrict__ win_off,
-                            const int *__restrict__ pass_rank, const int32_t *__restrict__ start,
-                            uint32_t *__restrict__ entries)
+// One segment dealt on its own: the LDS-bank-aware order of plan.cpp::bank_order (wished class
+// (rank + t) mod classes, else the fullest class; inside a class in minor order).  off = first
+// step slot of the segment's (block, wave, window).
+__device__ void fill_segment_rowwise(const Geometry &g, int64_t s, int64_t e_, int rank, int64_t off, int gslot,
+                                     const int32_t *__restrict__ s_minor, const float *__restrict__ s_val,
+                                     uint32_t *__restrict__ entries)
 {
-    const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (id >= n_slots * g.W) return;
-    const int64_t slot = id / g.W;
-    const int w = (int)(id % g.W);
-    const int32_t row = block_rows[slot];
-    if (row < 0) return;
-    const int64_t r0 = mptr[row], r1 = mptr[row + 1];
-    if (r0 == r1) return;
-    int64_t s, e_;
-    if (g.ring > 1) {   // ring mode: what the schedule gave this lane in epoch w
-        const int32_t *st = start + (size_t)slot * ((size_t)g.W + 1);
-        s = r0 + st[w];
-        e_ = r0 + st[w + 1];
-    } else {
-        const int32_t base = w * g.win_rows;
-        s = lower_bound_minor(s_minor, r0, r1, (int64_t)base);
-        e_ = lower_bound_minor(s_minor, s, r1, (int64_t)base + g.win_rows);
-    }
     const int n = (int)(e_ - s);
-    if (n == 0) return;
-    const int64_t b = slot / g.gpb;
-    const int gi = (int)(slot % g.gpb);
-    const int gslot = gi % g.gpw;
-    const size_t bw = (size_t)b * g.wpb + gi / g.gpw;
-    const int rank = pass_rank[gslot];
-    const int64_t off = win_off[bw * g.W + w];
     const bool ordered = g.n_classes > 1 && n > 2;
     int cnt[16];
     int64_t cur[16];
@@ -235,6 +207,186 @@ __global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restri
             e[0] = o16;
             e[1] = __float_as_uint(s_val[src]);
         }
+    }
+}
+
+// the segment of one lane group in one window: [s, e_) of the sorted arrays
+__device__ __forceinline__ void segment_bounds(const Geometry &g, int64_t slot, int w, int64_t r0, int64_t r1,
+                                               const int32_t *__restrict__ s_minor, const int32_t *__restrict__ start,
+                                               int64_t &s, int64_t &e_)
+{
+    if (g.ring > 1) {   // ring mode: what the schedule gave this lane in epoch w
+        const int32_t *st = start + (size_t)slot * ((size_t)g.W + 1);
+        s = r0 + st[w];
+        e_ = r0 + st[w + 1];
+    } else {
+        const int32_t base = w * g.win_rows;
+        s = lower_bound_minor(s_minor, r0, r1, (int64_t)base);
+        e_ = lower_bound_minor(s_minor, s, r1, (int64_t)base + g.win_rows);
+    }
+}
+
+// fill, one thread per (row, window) segment.  win_off[(block, wave), window] = first step
+// slot of that window's entries.
+__global__ void fill_kernel(Geometry g, int64_t n_slots, const int32_t *__restrict__ block_rows,
+                            const int64_t *__restrict__ mptr, const int32_t *__restrict__ s_minor,
+                            const float *__restrict__ s_val, const int64_t *__restrict__ win_off,
+                            const int *__restrict__ pass_rank, const int32_t *__restrict__ start,
+                            uint32_t *__restrict__ entries)
+{
+    const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (id >= n_slots * g.W) return;
+    const int64_t slot = id / g.W;
+    const int w = (int)(id % g.W);
+    const int32_t row = block_rows[slot];
+    if (row < 0) return;
+    const int64_t r0 = mptr[row], r1 = mptr[row + 1];
+    if (r0 == r1) return;
+    int64_t s, e_;
+    segment_bounds(g, slot, w, r0, r1, s_minor, start, s, e_);
+    if (e_ == s) return;
+    const int64_t b = slot / g.gpb;
+    const int gi = (int)(slot % g.gpb);
+    const int gslot = gi % g.gpw;
+    const size_t bw = (size_t)b * g.wpb + gi / g.gpw;
+    fill_segment_rowwise(g, s, e_, pass_rank[gslot], win_off[bw * g.W + w], gslot, s_minor, s_val, entries);
+}
+
+// fill with the joint bank assignment (plan.cpp::bank_order_joint).  A (block, wave, window) unit is
+// worked by gpw lanes -- lane m is lane group m of the sweep's wave -- and a 64-lane workgroup here
+// takes 64 / gpw units.  Every lane first sorts its segment by class into LDS (counts, per-class lists
+// of positions; the minors are fetched eight at a time so that the loop pays one memory latency per
+// eight nonzeros); then, position by position, the groups of a pass pick in turn -- one lane of each
+// pass at a time, its choice handed to the pass by a cross-lane read -- and note the sequence in LDS;
+// the entries are written afterwards, two nonzeros per 8- or 16-byte store, so that no global load
+// sits inside the serial part.  Segments longer than TILE_JOINT_MAX go the per-row way.
+template <int NC>
+__global__ __launch_bounds__(64) void fill_joint_kernel(Geometry g, int64_t n_units, const int32_t *__restrict__ block_rows,
+                                                        const int64_t *__restrict__ mptr,
+                                                        const int32_t *__restrict__ s_minor,
+                                                        const float *__restrict__ s_val,
+                                                        const int64_t *__restrict__ win_off,
+                                                        const int *__restrict__ pass_rank,
+                                                        const int *__restrict__ pass_of, const int32_t *__restrict__ start,
+                                                        uint32_t *__restrict__ entries)
+{
+    __shared__ uint8_t cnt[16 * 64], head[16 * 64];
+    __shared__ uint8_t pos[TILE_JOINT_MAX * 64], seq[TILE_JOINT_MAX * 64];
+    __shared__ int lane_of[64];                       // [unit of the workgroup][pass * rank] -> lane
+    const int l = threadIdx.x;
+    const int sub = l / g.gpw, m = l - sub * g.gpw;   // gpw divides 64
+    const int upw = 64 / g.gpw;
+    const int64_t unit = (int64_t)blockIdx.x * upw + sub;
+    const bool member = unit < n_units;
+    const int64_t bw = member ? unit / g.W : 0;
+    const int w = member ? (int)(unit % g.W) : 0;
+    const int rank = pass_rank[m], pass = pass_of[m];
+    lane_of[sub * g.gpw + pass * NC + rank] = l;      // 4 passes of NC groups = the gpw lanes of the unit
+    const int64_t slot = bw * g.gpw + m;
+    const int32_t row = member ? block_rows[slot] : -1;
+    int64_t s = 0, e_ = 0;
+    if (row >= 0) {
+        const int64_t r0 = mptr[row], r1 = mptr[row + 1];
+        if (r1 > r0) segment_bounds(g, slot, w, r0, r1, s_minor, start, s, e_);
+    }
+    const int n = (int)(e_ - s);
+    const bool joint = n > 0 && n <= TILE_JOINT_MAX;
+    const int64_t off = member ? win_off[unit] : 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cnt[c * 64 + l] = 0;
+    if (joint) {
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            int32_t mm[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mm[u] = j0 + u < n ? s_minor[s + j0 + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < n) {
+                    const int c = bank_class(g, mm[u]);
+                    seq[(j0 + u) * 64 + l] = (uint8_t)c;
+                    cnt[c * 64 + l]++;
+                }
+        }
+        int run = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { head[c * 64 + l] = (uint8_t)run; run += cnt[c * 64 + l]; }
+        for (int j = 0; j < n; ++j) {
+            const int c = seq[j * 64 + l];
+            pos[(int)(head[c * 64 + l]++) * 64 + l] = (uint8_t)j;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) head[c * 64 + l] -= cnt[c * 64 + l];
+    }
+    __syncthreads();
+    int max_n = joint ? n : 0;
+    for (int d = 32; d >= 1; d >>= 1) max_n = max(max_n, __shfl_xor(max_n, d, 64));
+    const int *my_lanes = lane_of + sub * g.gpw + pass * NC;
+    for (int t = 0; t < max_n; ++t) {
+        // tile_joint_pick with the keys of the position in registers: every lane builds its own at once, a class
+        // its pass has read is struck out of everybody's, and the lane whose turn it is takes the largest left
+        const bool active = joint && t < n;
+        const unsigned wish = ((unsigned)rank + (unsigned)t) & (unsigned)(NC - 1);
+        unsigned key[NC], best_any = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned k = active ? (unsigned)cnt[c * 64 + l] : 0u;
+            const unsigned d = ((unsigned)c - wish) & (unsigned)(NC - 1);
+            key[c] = k ? (k << 4) | (15u - d) : 0u;
+            best_any = max(best_any, key[c]);
+        }
+        int my_c = 0;
+        for (int a = 0; a < NC; ++a) {
+            const int rk = (a + t) & (NC - 1);
+            unsigned best_free = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) best_free = max(best_free, key[c]);
+            const unsigned k = best_free ? best_free : best_any;
+            const int mine_c = (int)((wish + (15u - (k & 15u))) & (unsigned)(NC - 1));
+            const bool mine = active && rank == rk;
+            if (mine) my_c = mine_c;
+            const int c = __shfl(mine ? mine_c : -1, my_lanes[rk], 64);
+#pragma unroll
+            for (int c2 = 0; c2 < NC; ++c2) key[c2] = c2 == c ? 0u : key[c2];
+        }
+        if (active) {
+            const int q = head[my_c * 64 + l];
+            seq[t * 64 + l] = pos[q * 64 + l];
+            head[my_c * 64 + l] = (uint8_t)(q + 1);
+            cnt[my_c * 64 + l]--;
+        }
+    }
+    if (joint) {
+        const uint32_t pad = g.ring > 1 ? (uint32_t)(w % g.ring) * (uint32_t)g.slot16 : 0u;
+        for (int t0 = 0; t0 < n; t0 += 8) {
+            int32_t mm[8];
+            float vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = t0 + u < n;
+                const int64_t j = s + (on ? seq[(t0 + u) * 64 + l] : 0);
+                mm[u] = on ? s_minor[j] : -1;
+                vv[u] = on ? s_val[j] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                if (t0 + u >= n) break;
+                const uint32_t o0 = dev_off16(g, mm[u]);
+                const uint32_t o1 = mm[u + 1] >= 0 ? dev_off16(g, mm[u + 1]) : pad;
+                const size_t step_slot = (size_t)off + (size_t)((t0 + u) >> 1) * g.gpw + m;
+                if (g.packed) {
+                    uint2 e;
+                    e.x = o0 | (o1 << 16);
+                    e.y = (uint32_t)vv[u] | ((uint32_t)vv[u + 1] << 16);
+                    *reinterpret_cast<uint2 *>(entries + step_slot * 2) = e;
+                } else {
+                    uint4 e;
+                    e.x = o0; e.y = __float_as_uint(vv[u]); e.z = o1; e.w = __float_as_uint(vv[u + 1]);
+                    *reinterpret_cast<uint4 *>(entries + step_slot * 4) = e;
+                }
+            }
+        }
+    } else if (n > 0) {
+        fill_segment_rowwise(g, s, e_, rank, off, m, s_minor, s_val, entries);
     }
 }
 
@@ -381,7 +533,26 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
             hipLaunchKernelGGL(ring_pad_kernel, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, st, g,
                                (int64_t)P.n_blocks * P.wpb, d_woff.as<int64_t>(), d_steps32.as<unsigned>(),
                                static_cast<uint32_t *>(d_entries));
-        if (n_segments > 0)
+        const bool joint = shape.bank_order == 2 && lpc <= 8;
+        const std::vector<int> pass_of = tile_pass_of(lpc, P.gpw);
+        Tmp d_pass(pass_of.size() * 4);
+        PD_CHECK(hipMemcpyAsync(d_pass.p, pass_of.data(), pass_of.size() * 4, hipMemcpyHostToDevice, st));
+        if (n_segments > 0 && joint) {
+            // gpw lanes per (block, wave, window)
+            const size_t upw = (size_t)(64 / P.gpw);
+#define SCHPF_FILL_JOINT(NC)                                                                                        \
+    hipLaunchKernelGGL(fill_joint_kernel<NC>, dim3((unsigned)((n_steps + upw - 1) / upw)), dim3(64), 0, st, g, (int64_t)n_steps, \
+                       d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, s_val, d_woff.as<int64_t>(),            \
+                       d_rank.as<int>(), d_pass.as<int>(), d_start.as<int32_t>(), static_cast<uint32_t *>(d_entries))
+            if (n_steps > 0x7fffffffull) throw std::invalid_argument("too many (wave, window) units for the joint fill");
+            switch (g.n_classes) {
+            case 16: SCHPF_FILL_JOINT(16); break;
+            case 8: SCHPF_FILL_JOINT(8); break;
+            case 4: SCHPF_FILL_JOINT(4); break;
+            default: SCHPF_FILL_JOINT(2); break;
+            }
+#undef SCHPF_FILL_JOINT
+        } else if (n_segments > 0)
             hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
                                d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, s_val, d_woff.as<int64_t>(),
                                d_rank.as<int>(), d_start.as<int32_t>(), static_cast<uint32_t *>(d_entries));

@@ -110,7 +110,7 @@ def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_
     om = np.empty(nnz, np.int32); on = np.empty(nnz, np.int32); ov = np.empty(nnz, np.float32)
     oprow = np.empty(nnz, np.int32); otask = np.empty(nnz, np.int32)
     pfirst = np.empty(n_major, np.int32); pcount = np.empty(n_major, np.int32)
-    stats = (ctypes.c_int64 * 6)()
+    stats = (ctypes.c_int64 * 8)()
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     _lib.check(lib.schpf_debug_tile_expand(nnz, p(major), p(minor), p(val), n_major, n_minor, lpc, wpb,
                                            win_rows, target_tasks, ring, slot_bytes, p(om), p(on), p(ov), p(oprow), p(otask),
@@ -125,8 +125,9 @@ def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_
                          [(4, 8, 64, 64, 1, 0), (2, 4, 37, 1, 1, 0), (1, 1, 1000, 7, 1, 0), (8, 2, 5, 1000, 1, 0),
                           (16, 8, 300, 16, 1, 0),
                           (2, 4, 0, 16, -2, 8192), (1, 1, 0, 1, -2, 1024), (2, 16, 0, 1000, -2, 77824), (4, 8, 0, 64, -3, 4000)])
-@pytest.mark.parametrize("coo_order", ["shuffled", "row-major", "col-major"])
-def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_order):
+@pytest.mark.parametrize("coo_order,bank_order", [("shuffled", 2), ("row-major", 2), ("col-major", 2), ("shuffled", 1), ("shuffled", 0)])
+def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_order, bank_order, monkeypatch):
+    monkeypatch.setenv("SCHPF_BANK_ORDER", str(bank_order))   # order inside a segment: minor / per row / jointly per LDS pass
     X = synthetic_counts(257, 1031, 0.04, seed=5)
     # the plan builder has fast paths for input already sorted by (row, col) / (col, row)
     perm = {"shuffled": np.random.RandomState(0).permutation(X.nnz),
@@ -135,7 +136,7 @@ def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_or
     for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
         om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, tasks,
                                                                    ring, slot_bytes)
-        n_tasks, n_blocks, n_windows, pstride, slots, wpt = st
+        n_tasks, n_blocks, n_windows, pstride, slots, wpt = st[:6]
         if abs(ring) > 1:
             win_rows = (slot_bytes - 64) // 160     # rows of a ring slot (its last 64 bytes stay free); the hook itself checks that every entry of
             #                                  an epoch lies in a slot that is readable during that epoch
@@ -155,6 +156,26 @@ def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_or
         owner = np.full(n_tasks * (64 // lpc) * wpb, -1)
         owner[oprow] = om
         assert np.array_equal(owner[oprow], om)
+
+
+@pytest.mark.parametrize("lpc,row_slots", [(2, 10), (1, 5), (4, 28)])
+@pytest.mark.parametrize("ring,slot_bytes,win_rows", [(-2, 77824, 0), (1, 0, 900)])
+def test_joint_bank_order_has_the_fewest_modelled_conflicts(lpc, row_slots, ring, slot_bytes, win_rows, monkeypatch):
+    """The three orders inside a segment hold the same nonzeros (round trip above); under the LDS model of
+    plan.cpp (the lane groups of a pass read one table row each, rows of one class are served one after the
+    other) the per-row rotation must beat minor order and the joint assignment must beat both -- at the shipped
+    shapes: f64 K = 20 (two lanes per 160-byte row), f32 K = 20 (one lane per 80-byte row), f64 K = 50."""
+    X = synthetic_counts(6000, 1500, 0.05, seed=8)
+    monkeypatch.setenv("SCHPF_DEBUG_ROW_SLOTS", str(row_slots))
+    if ring == 1:
+        win_rows = win_rows * 10 // row_slots
+    extra = {}
+    for order in (0, 1, 2):
+        monkeypatch.setenv("SCHPF_BANK_ORDER", str(order))
+        for major, minor, nM, nm in ((X.row, X.col, 6000, 1500), (X.col, X.row, 1500, 6000)):
+            st = expand_tile(major, minor, X.data.astype(np.float32), nM, nm, lpc, 16, win_rows, 4, ring, slot_bytes)[-1]
+            extra[order] = extra.get(order, 0.0) + st[7] / st[6] / 2
+    assert extra[2] < 0.8 * extra[1] < 0.8 * extra[0], extra
 
 
 def test_tile_plan_tiny():
