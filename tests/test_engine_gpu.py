@@ -833,12 +833,18 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
 
 @only_plans("tile", "half")
 @pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
-@pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True)])
-def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_order, dtype, K, big):
+@pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True),
+                                         (np.float64, 50, False)])
+@pytest.mark.parametrize("bank_order", [2, 1])
+def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_order, dtype, K, big, bank_order):
     """The plan built by device passes (plan_device.hip: radix sort, step counts, bank-ordered
     fill) is the host builder's plan bit for bit: same entry order => same summation order => the
     engines agree in every bit after three iterations, from a host-drawn t=0 included (that path
-    uses the plan's sort permutation)."""
+    uses the plan's sort permutation).  bank_order 2 = the joint assignment over the lane groups of an
+    LDS pass (wave-parallel fill_joint_kernel against the sequential plan.cpp::bank_order_joint; one, two
+    and four lanes per row), 1 = the per-row rule (also what segments of > 128 nonzeros fall back to:
+    the col-major case has them)."""
+    monkeypatch.setenv("SCHPF_BANK_ORDER", str(bank_order))
     from scipy.sparse import coo_matrix
     # col-major input also gets long segments (40 % filled: > 192 nonzeros per row and window)
     X = synthetic_counts(600, 2600, 0.4, seed=11) if coo_order == "col-major" else synthetic_counts(2500, 1800, 0.05, seed=11)
