@@ -779,7 +779,8 @@ template <typename T> struct Engine final : schpf_ctx {
         const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, share, (double)nnz, resident,
                                                                1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
                                                                partial_seconds,
-                                                               expect_sharded ? 4 : 6, 1.12, 32, expect_sharded);
+                                                               expect_sharded ? 4 : 6, 1.12, 32, expect_sharded,
+                                                               env_int("SCHPF_TAPER", 30) / 100.0);
         if (c.ranges[0] <= 0 || c.ranges[1] <= 0) return false;
         for (int s = 0; s < 2; ++s) { ranges[s] = c.ranges[s]; half[s] = c.half[s] ? 1 : 0; }
         // exploration: fix the ranges by hand, keep the model's schedules (tools/explore.py)
@@ -803,6 +804,7 @@ template <typename T> struct Engine final : schpf_ctx {
         sh.row_slots = (int)(row_bytes / 16);
         sh.bank_order = env_int("SCHPF_BANK_ORDER", 2);   // 0 minor order, 1 per row, 2 jointly per LDS pass (plan.h)
         sh.allow_packed = env_int("SCHPF_PACK", 1) != 0;
+        sh.taper = env_int("SCHPF_TAPER", 30) / 100.0;   // window ranges of unequal length (plan.h tile_range_starts), per cent
         sh.win_rows = (int)std::max<size_t>(1, (size_t)lds_kb * 1024 / row_bytes);
         // tasks per orientation: a few rounds of the 256 CUs for big problems; about one round when
         // there are few (block, window) pairs (1/8 shard of C3: 1024 -> 256 tasks is 10 % faster:
@@ -1875,6 +1877,8 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         sh.ring = ring < 0 ? -ring : ring; sh.sync_stage = sh.ring > 1 ? 1 : 0; sh.slot_bytes = slot_bytes;
         sh.allow_packed = getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true;
         sh.bank_order = env_int("SCHPF_BANK_ORDER", 2);
+        sh.taper = env_int("SCHPF_TAPER", 0) / 100.0;
+        if (sh.taper > 0.0) sh.slots = 1;   // tapered ranges are for orientations with more tasks than workgroups (plan.h)
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, false, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
         // the LDS model of plan.cpp::bank_order: the lane groups of a pass read one row each per half step; rows of

@@ -407,6 +407,30 @@ static void bank_order_joint(const TilePlanHost &P, int gpw, const int32_t *cons
 // ---- pieces of the tile plan that do not touch the nonzeros; shared by the host builder below
 // ---- and the device builder (plan_device.hip)
 
+std::vector<int32_t> tile_range_starts(int W, int64_t wpt, double taper)
+{
+    wpt = std::max<int64_t>(1, std::min<int64_t>(wpt, std::max(W, 1)));
+    const int R = std::max(1, (int)((W + wpt - 1) / wpt));
+    std::vector<int32_t> start((size_t)R + 1, 0);
+    // with few ranges per block the long ones would outlast the launch: equal cuts there
+    if (!(taper > 0.0) || R < 6) {
+        for (int r = 0; r <= R; ++r) start[(size_t)r] = (int32_t)std::min<int64_t>((int64_t)r * wpt, W);
+        return start;
+    }
+    taper = std::min(taper, 0.9);
+    const double mean = (double)W / R;
+    double cum = 0.0;
+    for (int r = 0; r < R; ++r) {
+        cum += mean * (1.0 + taper * (1.0 - 2.0 * r / (R - 1)));
+        int64_t b = (int64_t)std::floor(cum + 0.5);
+        b = std::max<int64_t>(b, (int64_t)start[(size_t)r] + 1);         // no empty range
+        b = std::min<int64_t>(b, (int64_t)W - (R - 1 - r));              // room for the ranges that follow
+        start[(size_t)r + 1] = (int32_t)b;
+    }
+    start[(size_t)R] = W;
+    return start;
+}
+
 // dimensions, rows by length -> blocks, tasks, partial-row bookkeeping; P.steps zeroed
 void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, const TileShape &shape,
                      const int64_t *mptr)
@@ -471,7 +495,11 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
         }
     }
     P.windows_per_task = (int)wpt;
-    const int n_ranges = (int)((W + wpt - 1) / wpt);
+    P.range_start = tile_range_starts(W, wpt, tile_taper_applies(((W + wpt - 1) / wpt) * P.n_blocks, shape.slots) ? shape.taper : 0.0);
+    const int n_ranges = (int)P.range_start.size() - 1;
+    P.range_end_of_window.assign((size_t)W, 0);
+    for (int r = 0; r < n_ranges; ++r)
+        for (int w = P.range_start[(size_t)r]; w < P.range_start[(size_t)r + 1]; ++w) P.range_end_of_window[(size_t)w] = P.range_start[(size_t)r + 1];
     P.n_tasks = (int64_t)n_ranges * P.n_blocks;
     P.n_partial_rows = P.n_tasks * gpb;
     P.pstride = P.n_blocks * gpb;   // consecutive ranges of one block are n_blocks tasks apart
@@ -482,8 +510,8 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
         for (int64_t b = 0; b < P.n_blocks; ++b) {
             const size_t t = (size_t)r * P.n_blocks + b;
             P.task_block[t] = (int32_t)b;
-            P.task_w0[t] = (int32_t)(r * wpt);
-            P.task_w1[t] = (int32_t)std::min<int64_t>((r + 1) * wpt, W);
+            P.task_w0[t] = P.range_start[(size_t)r];
+            P.task_w1[t] = P.range_start[(size_t)r + 1];
         }
     P.pfirst.assign((size_t)n_major, 0);
     P.pcount.assign((size_t)n_major, n_ranges);
@@ -594,7 +622,7 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
                                const std::vector<double> block_share[2],
                                double nnz, int resident, double nnz_per_second, double task_seconds,
                                const double partial_seconds[2], int min_half_per_task, double window_penalty,
-                               int max_ranges, bool separate_launches)
+                               int max_ranges, bool separate_launches, double taper)
 {
     struct Pool { int64_t n_tasks; int s; int64_t r, wpt, W; double per_nnz; bool half; };
     auto pool = [&](int s, int r, Pool &p) {
@@ -615,11 +643,12 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
         for (int i = 0; i < n_pools; ++i) {
             const Pool &p = pools[i];
             const std::vector<double> &share = block_share[p.s];
+            const std::vector<int32_t> starts = tile_range_starts((int)p.W, p.wpt, tile_taper_applies(p.n_tasks, separate_launches ? resident : resident / 2) ? taper : 0.0);
             for (int64_t b = 0; b < blocks[p.s]; ++b) {
                 const double block_nnz = nnz * (share.empty() ? 1.0 / (double)blocks[p.s] : share[(size_t)b]);
                 const double per_window = block_nnz / (double)p.W * p.per_nnz;
-                durations.insert(durations.end(), (size_t)(p.r - 1), (double)p.wpt * per_window + task_seconds);
-                durations.push_back((double)(p.W - p.wpt * (p.r - 1)) * per_window + task_seconds);
+                for (size_t r = 0; r + 1 < starts.size(); ++r)
+                    durations.push_back((double)(starts[r + 1] - starts[r]) * per_window + task_seconds);
             }
         }
         std::sort(durations.begin(), durations.end(), std::greater<double>());
@@ -671,7 +700,6 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
 int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
 {
     const int W = P.n_windows, wpb = P.wpb, gpw = P.gpw;
-    const int64_t wpt = P.windows_per_task;
     const int nth = host_threads();
     // work of a task: its workgroup runs, window by window, as long as its slowest wave (+ a
     // staging of the window); task_order (longest first) feeds the merged cell+gene launch
@@ -706,9 +734,10 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
             for (int v = 0; v < wpb; ++v) {
                 const size_t bw = (size_t)b * wpb + v;
                 int64_t off = wave_off[bw];
+                int r = 0;
                 for (int w = 0; w < W; ++w) {
-                    const size_t tv = ((size_t)(w / wpt) * P.n_blocks + b) * wpb + v;
-                    if (w % wpt == 0) P.task_wave_off[tv] = off;
+                    if (w == P.range_start[(size_t)r + 1]) ++r;
+                    if (w == P.range_start[(size_t)r]) P.task_wave_off[((size_t)r * P.n_blocks + b) * wpb + v] = off;
                     off += tile_stored_steps(P, P.steps[bw * W + w]) * gpw;
                 }
             }
@@ -773,10 +802,9 @@ template <typename CntBelow>
 static void ring_schedule_block(const TilePlanHost &P, int64_t b, CntBelow cnt_below, int32_t *start, uint32_t *T)
 {
     const int W = P.n_windows, gpb = P.gpb;
-    const int64_t wpt = P.windows_per_task;
     std::vector<int32_t> done((size_t)gpb, 0);
     for (int e = 0; e < W; ++e) {
-        const int w1 = (int)std::min<int64_t>((e / wpt + 1) * wpt, W);   // end of the task e belongs to
+        const int w1 = P.range_end_of_window[(size_t)e];   // end of the task e belongs to
         const int hor = std::min(e + P.look + 1, w1);
         const int span = P.gpw;   // the waves meet at the barrier anyway: every wave has its own T_e
         for (int g0 = 0; g0 < gpb; g0 += span) {

@@ -142,7 +142,9 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 struct TilePlanHost {
     int n_major = 0, n_minor = 0;
     int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
-    int win_rows = 0, n_windows = 0, windows_per_task = 0;
+    int win_rows = 0, n_windows = 0, windows_per_task = 0;   // windows_per_task: the uniform cut the ranges derive from
+    std::vector<int32_t> range_start;     // [n_ranges + 1] window ranges (tasks per block), tile_range_starts
+    std::vector<int32_t> range_end_of_window;   // [n_windows] end of the range a window belongs to
     int ring = 1, slot16 = 0;             // half-window schedule: slots in the LDS, 16-byte units per slot
     int look = 0;                         // ... sub-windows beyond the epoch's own a row may work ahead in (ring - 1)
     int sync_stage = 0;                   // ... 1 whenever ring > 1 (slots refilled AT the epoch boundary)
@@ -175,6 +177,7 @@ struct TileShape {
                             // target_tasks and the rounding by `slots` are then not consulted
     int bank_order = 1;
     bool allow_packed = true;
+    double taper = 0.0;     // > 0: window ranges of unequal length, (1 + taper) .. (1 - taper) x the mean (tile_range_starts)
 };
 // How many window ranges (tasks per block) each orientation of a ONE-LAUNCH iteration should have.  The
 // merged launch runs its tasks longest first on `resident` workgroups that draw from one list, so the
@@ -198,7 +201,7 @@ RangeChoice choose_task_ranges(const int64_t blocks[2], const int64_t half_windo
                                const std::vector<double> block_share[2],
                                double nnz, int resident, double nnz_per_second, double task_seconds,
                                const double partial_seconds[2], int min_half_per_task, double window_penalty,
-                               int max_ranges, bool separate_launches);
+                               int max_ranges, bool separate_launches, double taper = 0.0);
 
 // Launch order (slot -> task) of the tile sweep over one or two plans' tasks that keeps the tasks
 // reading the SAME window range of the minor table on ONE XCD at the same time: an XCD's 32 compute
@@ -245,6 +248,16 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off);
 std::vector<int> tile_pass_rank(int lpc, int gpw);
 // the LDS pass (0..3) the lane group sits in, beside its rank inside that pass (tile_pass_rank)
 std::vector<int> tile_pass_of(int lpc, int gpw);
+// Window ranges of one block.  W windows in ranges of `wpt` (the last one shorter): n = ceil(W / wpt) ranges.
+// taper = 0, or fewer than six ranges: exactly that.  taper > 0: the same NUMBER of ranges, their lengths falling linearly from (1 + taper) to
+// (1 - taper) times the mean: the merged launch runs its tasks longest first on workgroups that draw from one list, so
+// the idle tail of the launch is about half the length of the LAST tasks started -- short ranges at the end of the
+// list fill the gaps the long ones leave (round 3: the tail was 10 % of the CU-time of the f32 launch, 3.7 % in f64).
+std::vector<int32_t> tile_range_starts(int W, int64_t wpt, double taper);
+// ... and only where the orientation has tasks for more than a round and a half of the workgroups it gets (`slots`,
+// TileShape::slots): in a single round unequal tasks ARE the imbalance (measured: 10k x 5k -10 %, a 1/8 shard of C3
+// -7 % with tapered ranges; C3 f32 +3.4 %, half of C3 +2 %, profiles/r03/ab_tapered_ranges.txt)
+inline bool tile_taper_applies(int64_t n_tasks, int slots) { return slots > 0 && 2 * n_tasks >= 3 * (int64_t)slots; }
 // joint bank assignment (bank_order = 2): segments longer than this are dealt on their own (bank_order = 1 rule)
 constexpr int TILE_JOINT_MAX = 128;
 // The pick of one lane group at position t (both builders): counts per class cnt[0..n_classes), classes already

@@ -70,7 +70,7 @@ __global__ void fill_i64_kernel(int64_t n, int64_t v, int64_t *__restrict__ out)
 
 struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
-    int ring, slot16, wpt, look;
+    int ring, slot16, look;
 };
 
 // LDS position of minor row m in 16-byte units (plan.h tile_off16)
@@ -128,6 +128,7 @@ __device__ __forceinline__ int bank_class(const Geometry &g, int32_t minor)
 __global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const int32_t *__restrict__ block_rows,
                                                             const int64_t *__restrict__ mptr,
                                                             const int32_t *__restrict__ s_minor,
+                                                            const int32_t *__restrict__ range_end,
                                                             unsigned *__restrict__ steps32, int32_t *__restrict__ start,
                                                             int *__restrict__ err)
 {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(1024) void ring_schedule_kernel(Geometry g, const i
         return lower_bound_minor(s_minor, lo + 1, lo + step < r1 ? lo + step : r1, bound);
     };
     for (int e = 0; e < g.W; ++e) {
-        const int w1 = min((e / g.wpt + 1) * g.wpt, g.W);
+        const int w1 = range_end[e];                  // end of the task e belongs to (plan.h range_end_of_window)
         const int hor = min(e + g.look + 1, w1);
         c_need = advance(c_need, ((int64_t)e + 1) * g.win_rows);
         if (c_hor < c_need) c_hor = c_need;
@@ -472,7 +473,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         while ((1 << g.lpc_shift) < lpc) ++g.lpc_shift;
         g.n_classes = shape.bank_order ? std::max(1, 16 / std::max(1, lpc)) : 1;
         g.row_slots = P.row_slots;
-        g.ring = P.ring; g.slot16 = P.slot16; g.wpt = P.windows_per_task;
+        g.ring = P.ring; g.slot16 = P.slot16;
         g.look = P.look;
         const bool ring = P.ring > 1;
         const int64_t n_slots = P.n_blocks * P.gpb;
@@ -489,9 +490,11 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         if (n_segments > 0 && !ring)
             hipLaunchKernelGGL(steps_kernel, dim3((unsigned)((n_segments + 255) / 256)), dim3(256), 0, st, g, n_slots,
                                d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, d_steps32.as<unsigned>(), d_err);
+        Tmp d_range_end((size_t)P.n_windows * 4);
+        PD_CHECK(hipMemcpyAsync(d_range_end.p, P.range_end_of_window.data(), (size_t)P.n_windows * 4, hipMemcpyHostToDevice, st));
         if (n_segments > 0 && ring)
             hipLaunchKernelGGL(ring_schedule_kernel, dim3((unsigned)P.n_blocks), dim3((unsigned)((P.gpb + 63) / 64 * 64)), 0, st, g,
-                               d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, d_steps32.as<unsigned>(),
+                               d_rows.as<int32_t>(), d_mptr.as<int64_t>(), s_minor, d_range_end.as<int32_t>(), d_steps32.as<unsigned>(),
                                d_start.as<int32_t>(), d_err);
         std::vector<uint32_t> steps32(n_steps + 1);
         PD_CHECK(hipMemcpyAsync(steps32.data(), d_steps32.p, (n_steps + 1) * 4, hipMemcpyDeviceToHost, st));

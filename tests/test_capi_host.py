@@ -125,9 +125,11 @@ def expand_tile(major, minor, val, n_major, n_minor, lpc, wpb, win_rows, target_
                          [(4, 8, 64, 64, 1, 0), (2, 4, 37, 1, 1, 0), (1, 1, 1000, 7, 1, 0), (8, 2, 5, 1000, 1, 0),
                           (16, 8, 300, 16, 1, 0),
                           (2, 4, 0, 16, -2, 8192), (1, 1, 0, 1, -2, 1024), (2, 16, 0, 1000, -2, 77824), (4, 8, 0, 64, -3, 4000)])
-@pytest.mark.parametrize("coo_order,bank_order", [("shuffled", 2), ("row-major", 2), ("col-major", 2), ("shuffled", 1), ("shuffled", 0)])
-def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_order, bank_order, monkeypatch):
+@pytest.mark.parametrize("coo_order,bank_order,taper", [("shuffled", 2, 0), ("row-major", 2, 40), ("col-major", 2, 0), ("shuffled", 1, 0),
+                                                        ("shuffled", 0, 0), ("shuffled", 2, 40), ("col-major", 2, 80)])
+def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_order, bank_order, taper, monkeypatch):
     monkeypatch.setenv("SCHPF_BANK_ORDER", str(bank_order))   # order inside a segment: minor / per row / jointly per LDS pass
+    monkeypatch.setenv("SCHPF_TAPER", str(taper))             # window ranges of unequal length (per cent)
     X = synthetic_counts(257, 1031, 0.04, seed=5)
     # the plan builder has fast paths for input already sorted by (row, col) / (col, row)
     perm = {"shuffled": np.random.RandomState(0).permutation(X.nnz),
@@ -149,9 +151,18 @@ def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_or
         j = (oprow - pfirst[om]) // pstride
         assert np.array_equal(pfirst[om] + j * pstride, oprow)
         assert np.all(j >= 0) and np.all(j < pcount[om])
-        assert np.array_equal(j, (on // win_rows) // wpt)            # task range <-> window
         assert n_windows == -(-nm // win_rows)
-        assert n_tasks == n_blocks * -(-n_windows // wpt)
+        n_ranges = -(-n_windows // wpt)
+        assert n_tasks == n_blocks * n_ranges
+        win = on // win_rows
+        if taper == 0:
+            assert np.array_equal(j, win // wpt)                     # task range <-> window: equal cuts
+        else:                                                        # tapered: ranges are intervals of windows, in order
+            assert np.array_equal(j, otask // n_blocks)
+            lo = np.full(n_ranges, n_windows); hi = np.full(n_ranges, -1)
+            np.minimum.at(lo, j, win); np.maximum.at(hi, j, win)
+            seen = hi >= 0
+            assert np.all(hi[seen][:-1] < lo[seen][1:])
         # partial rows are exclusive to one major
         owner = np.full(n_tasks * (64 // lpc) * wpb, -1)
         owner[oprow] = om
