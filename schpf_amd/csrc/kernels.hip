@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <climits>
 
 #include "kernels.h"
 
@@ -40,6 +41,38 @@ __device__ __forceinline__ double dev_digamma(double x)
     return log(x) - 0.5 * r - z * p - num / den;
 }
 
+// psi(x) - log(rate) with ONE logarithm: the recurrence leaves log(x') with x' >= 10, and log(x') - log(rate) =
+// log(x' / rate) costs a division instead of a second log (~70 instructions of the update kernel, which is bound
+// by its instruction count: profiles/r03/update_kernel_variant.txt).  At least as accurate as the difference of
+// two rounded logarithms.
+__device__ __forceinline__ double dev_digamma_less_log(double x, double rate)
+{
+    double num = 0.0, den = 1.0;
+    while (x < 10.0) {
+        num = fma(num, x, den);
+        den *= x;
+        x += 1.0;
+    }
+    const double r = 1.0 / x;
+    const double z = r * r;
+    double p = 8.33333333333333333333E-2;
+    p = p * z - 2.10927960927960927961E-2;
+    p = p * z + 7.57575757575757575758E-3;
+    p = p * z - 4.16666666666666666667E-3;
+    p = p * z + 3.96825396825396825397E-3;
+    p = p * z - 8.33333333333333333333E-3;
+    p = p * z + 8.33333333333333333333E-2;
+    return log(x / rate) - 0.5 * r - z * p - num / den;
+}
+
+// order-preserving integer image of a float (and back): integer max instead of canonicalising v_max_f64 pairs
+__device__ __forceinline__ int float_order_key(float f)
+{
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float float_from_order_key(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
 // ------------------------------------------------------- fused Gamma update + tables
 // One thread per (row, factor).  Replaces, for one side (theta or beta) and in one
 // launch: compute_loading_shape_update (hpf_numba.py:128-156; here only the fixed-order
@@ -52,16 +85,17 @@ __device__ __forceinline__ double dev_digamma(double x)
 template <typename T, int SRC>
 __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
 {
-    extern __shared__ double lds[];  // [rb*K] E, [rb*K] L, [K] column sums, [K] sums of the other side
+    // [rb][KS2] E (row stride K rounded up to even), [rb][KS4] order keys of L (int; stride K rounded up to 4) -- rows
+    // that ds_read_b128 can walk --, [K] sums of the other side
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int K = a.K, KP = a.KP, rb = a.rows_per_block;
+    const int KS2 = (K + 1) & ~1, KS4 = (K + 3) & ~3;
     double *sE = lds;
-    double *sL = lds + (size_t)rb * K;
-    double *sC = sL + (size_t)rb * K;
-    double *sS = sC + K;
+    int *sKey = reinterpret_cast<int *>(lds + (size_t)rb * KS2);
+    double *sS = lds + (size_t)rb * KS2 + (size_t)rb * KS4 / 2;
     const int t = threadIdx.x;
     const int r = t / K, k = t - r * K;
     const bool lane_on = r < rb;
-    if (t < K) sC[t] = 0.0;
     if (SRC != SRC_NONE && a.s_other_nb > 0) {
         // the other side's column sums from its per-block partials, in a fixed order that is the same
         // in every block: thread (r, k) takes blocks r, r + rb, ...; then factor k's rb values in turn
@@ -94,10 +128,15 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
                                  ? (a.s_other_nb > 0 ? sS[k] : (a.s_other_t ? (double)a.s_other_t[k] : a.s_other[k]))
                                  : 0.0;
     const int groups = (a.n + rb - 1) / rb;
+    if (lane_on && k == 0) {   // the rows' padding: neutral for the sum and for the maximum
+        for (int q = K; q < KS2; ++q) sE[r * KS2 + q] = 0.0;
+        for (int q = K; q < KS4; ++q) sKey[r * KS4 + q] = INT_MIN;
+    }
+    double csum = 0.0;   // this thread's share of the block's column sum of E: its (r, k) over the groups it takes
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int row = grp * rb + r;
         const bool on = lane_on && row < a.n;
-        double E = 0.0, L = -INFINITY;
+        double E = 0.0, L = 0.0;
         if (on) {
             double shape, rate;
             if (SRC == SRC_NONE) {
@@ -122,34 +161,47 @@ __global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
                 rate = (double)(T)rate;
             }
             E = shape / rate;
-            L = dev_digamma(shape) - log(rate);   // psi in double whatever T is (hpf_numba.py:16-18)
+            L = dev_digamma_less_log(shape, rate);   // psi in double whatever T is (hpf_numba.py:16-18)
             a.tab_e[(size_t)row * KP + k] = (T)E;
             a.tab_log[(size_t)row * KP + k] = (T)L;
             E = (double)(T)E;
             L = (double)(T)L;
-            sE[r * K + k] = E;
-            sL[r * K + k] = L;
+            sE[r * KS2 + k] = E;
+            sKey[r * KS4 + k] = float_order_key((float)L);
         }
         __syncthreads();
         if (on) {
-            double mx = sL[r * K];
-            for (int q = 1; q < K; ++q) mx = fmax(mx, sL[r * K + q]);
-            a.tab_exp[(size_t)row * KP + k] = (T)exp(L - mx);
-            if (k == 0 && SRC != SRC_NONE) {
-                double sum = 0.0;
-                for (int q = 0; q < K; ++q) sum += sE[r * K + q];
-                a.cap_rate_out[row] = (T)(a.cap_prior_rate + sum);
+            // every thread of a row walks the row once: the shift of the exponentials (the row's largest L, rounded to
+            // float -- any shift within a few units of the maximum serves, it cancels in phi) and the row's sum of E
+            const double2 *__restrict__ e2 = reinterpret_cast<const double2 *>(sE + r * KS2);
+            const int4 *__restrict__ k4 = reinterpret_cast<const int4 *>(sKey + r * KS4);
+            int mk = INT_MIN;
+            double sum = 0.0;
+#pragma unroll 4
+            for (int q = 0; q < KS2 / 2; ++q) {
+                const double2 v = e2[q];
+                sum += v.x;
+                sum += v.y;
             }
+#pragma unroll 2
+            for (int q = 0; q < KS4 / 4; ++q) {
+                const int4 v = k4[q];
+                mk = max(mk, max(max(v.x, v.y), max(v.z, v.w)));
+            }
+            a.tab_exp[(size_t)row * KP + k] = (T)exp(L - (double)float_from_order_key(mk));
+            if (k == 0 && SRC != SRC_NONE) a.cap_rate_out[row] = (T)(a.cap_prior_rate + sum);
         }
-        if (t < K) {
-            const int nr = min(rb, a.n - grp * rb);
-            double c = 0.0;
-            for (int q = 0; q < nr; ++q) c += sE[q * K + t];
-            sC[t] += c;
-        }
+        csum += E;
         __syncthreads();
     }
-    if (t < K) a.colsum_part[(size_t)blockIdx.x * K + t] = sC[t];
+    // column sums of E over the block's rows: one pass over the rb shares at the end instead of one per group
+    if (lane_on) sE[r * K + k] = csum;
+    __syncthreads();
+    if (t < K) {
+        double c = 0.0;
+        for (int q = 0; q < rb; ++q) c += sE[q * K + t];
+        a.colsum_part[(size_t)blockIdx.x * K + t] = c;
+    }
 }
 
 // colsum_part [nblocks, K] -> out[K] (double), fixed order.  One workgroup per factor: every
@@ -437,7 +489,7 @@ static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 25
 
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st)
 {
-    const size_t lds = ((size_t)2 * a.rows_per_block * a.K + 2 * a.K) * sizeof(double);
+    const size_t lds = ((size_t)2 * a.rows_per_block * (a.K + 3) + 2 * a.K) * sizeof(double);   // E rows, key rows, sums (padded strides)
     dim3 grid((unsigned)nblocks), block(256);
     if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE>), grid, block, lds, st, a);
     else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS>), grid, block, lds, st, a);
