@@ -638,62 +638,77 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i0), sub, bA);
                 load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i1), sub, bB);
             }
-            for (int p = 0; p < steps; p += RING) {
+            // one step of the pipeline; I = position in the entry ring (a compile-time constant: the register
+            // arrays are indexed with it)
+            auto pipe_step = [&](auto I_) {
+                constexpr int I = decltype(I_)::value;
+                    const E cn = ring[(I + 1) % RING];
+                    unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
+                    // counts alternate between two register pairs (RING is even), no copies
+                    xc[(I + 1) & 1][0] = EF::val(cn, 0); xc[(I + 1) & 1][1] = EF::val(cn, 1);
+                    asm volatile("" : "+v"(n0), "+v"(n1), "+v"(xc[(I + 1) & 1][0]), "+v"(xc[(I + 1) & 1][1]));
+                    const T x0 = (T)xc[I & 1][0], x1 = (T)xc[I & 1][1];
+                    // both normalisers first: two independent dot / reciprocal chains in flight
+                    // (measured -1 % f64, -3 % f32 against finishing nonzero A before starting B:
+                    // profiles/r02/ab_step_variants.log).  No test of the normaliser here: a
+                    // product-form s that underflowed (zero / denormal) makes the reciprocal inf,
+                    // and inf * b or 0 * inf poisons EVERY accumulator of every lane of the group
+                    // (inf or NaN) -- detected once, after the task, and the group is then redone by
+                    // the cold path.  A small but normal s is exact enough: its largest term is a
+                    // normal number.
+                    const T s0 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bA);
+                    const T s1 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bB);
+                    if (MODE == MODE_PHI) {
+                        const T q0 = fast_div(x0, s0);
+                        const T q1 = fast_div(x1, s1);
+                        if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q0, bA[0], acc[0]); acc[1] = fma_t(q0, bA[KL - 1], acc[1]); } else
 #pragma unroll
-                for (int i = 0; i < RING; ++i) {
-                    // slot i was decoded one step ago: refill it; decode the NEXT step's slot.  Past the
-                    // window's last step that is the next window's entry or padding: its indices
-                    // are in range, the rows read with them are never used
-                    if (SCHPF_ABLATE != 4) ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);
-                    if (p + i < steps) {                               // scalar branch
-                        const E cn = ring[(i + 1) % RING];
-                        unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
-                        // counts alternate between two register pairs (RING is even), no copies
-                        xc[(i + 1) & 1][0] = EF::val(cn, 0); xc[(i + 1) & 1][1] = EF::val(cn, 1);
-                        asm volatile("" : "+v"(n0), "+v"(n1), "+v"(xc[(i + 1) & 1][0]), "+v"(xc[(i + 1) & 1][1]));
-                        const T x0 = (T)xc[i & 1][0], x1 = (T)xc[i & 1][1];
-                        // both normalisers first: two independent dot / reciprocal chains in flight
-                        // (measured -1 % f64, -3 % f32 against finishing nonzero A before starting B:
-                        // profiles/r02/ab_step_variants.log).  No test of the normaliser here: a
-                        // product-form s that underflowed (zero / denormal) makes the reciprocal inf,
-                        // and inf * b or 0 * inf poisons EVERY accumulator of every lane of the group
-                        // (inf or NaN) -- detected once, after the task, and the group is then redone by
-                        // the cold path.  A small but normal s is exact enough: its largest term is a
-                        // normal number.
-                        const T s0 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bA);
-                        const T s1 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bB);
-                        if (MODE == MODE_PHI) {
-                            const T q0 = fast_div(x0, s0);
-                            const T q1 = fast_div(x1, s1);
-                            if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q0, bA[0], acc[0]); acc[1] = fma_t(q0, bA[KL - 1], acc[1]); } else
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
-                            step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
-                            // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q1, bB[0], acc[0]); acc[1] = fma_t(q1, bB[KL - 1], acc[1]); } else
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
-                            step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
-                        } else {
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
-                            load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
-                        }
-                        if (MODE == MODE_LLH) {
-                            if (LPC == 1) {
-                                if (x0 > T(0)) lacc.add((double)x0, (double)s0);
-                                if (x1 > T(0)) lacc.add((double)x1, (double)s1);
-                            } else {
-                                // every lane of the group knows s0 and s1: lane 0 takes the first
-                                // nonzero, lane 1 the second
-                                const T sm = (sub & 1) ? s1 : s0;
-                                const T xm = (sub & 1) ? x1 : x0;
-                                if (sub < 2 && xm > T(0)) lacc.add((double)xm, (double)sm);
-                            }
-                        }
+                        for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
+                        step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
+                        // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated
                         __builtin_amdgcn_sched_barrier(0);
+                        if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q1, bB[0], acc[0]); acc[1] = fma_t(q1, bB[KL - 1], acc[1]); } else
+#pragma unroll
+                        for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
+                        step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
+                    } else {
+                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
+                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
                     }
-                }
+                    if (MODE == MODE_LLH) {
+                        if (LPC == 1) {
+                            if (x0 > T(0)) lacc.add((double)x0, (double)s0);
+                            if (x1 > T(0)) lacc.add((double)x1, (double)s1);
+                        } else {
+                            // every lane of the group knows s0 and s1: lane 0 takes the first
+                            // nonzero, lane 1 the second
+                            const T sm = (sub & 1) ? s1 : s0;
+                            const T xm = (sub & 1) ? x1 : x0;
+                            if (sub < 2 && xm > T(0)) lacc.add((double)xm, (double)sm);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+            };
+            // whole turns of the ring run without a branch per step: with the four guarded steps in one loop
+            // body the compiler gave the row registers different homes on different paths and paid for it with
+            // 10 v_mov_b32 per step in the float32 kernel (hipcc -S; 16 % of its VALU instructions)
+            int p = 0;
+            for (; p + RING <= steps; p += RING) {
+#define SCHPF_PIPE_STEP(I)                                                                              \
+    if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
+    pipe_step(std::integral_constant<int, I>{});
+                SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
+#undef SCHPF_PIPE_STEP
+            }
+            if (p < steps) {
+                // the ragged turn: slot i was decoded one step ago: refill it; decode the NEXT step's slot.  Past
+                // the window's last step that is the next window's entry or padding: its indices are in range, the
+                // rows read with them are never used
+#define SCHPF_PIPE_STEP(I)                                                                              \
+    if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
+    if (p + I < steps) pipe_step(std::integral_constant<int, I>{});
+                SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
+#undef SCHPF_PIPE_STEP
             }
         } else
         for (int p = 0; p < steps; p += RING) {
