@@ -645,12 +645,15 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         const schpf::TileShape sh_c = tile_shape(N, G, false, ranges[0], half[0]),
                                sh_g = tile_shape(G, N, true, ranges[1], half[1]);
-        for (int side = 0; side < 2; ++side) {
+        // the two orientations are independent (the COO is only read): the gene side on a helper thread with a
+        // stream of its own, so that the builders' host round trips (run pointers, step counts, allocations) and
+        // their short kernels overlap instead of adding up (SCHPF_PLAN_THREADS=1: one after the other)
+        auto build_side = [&](int side, hipStream_t st) {
             TileDev &td = side == 0 ? tcell : tgene;
             void *e = nullptr, *s = nullptr, *o = nullptr;
             size_t eb = 0;
             const bool presorted = side == 0 ? rc_sorted : cr_sorted;
-            schpf::build_tile_plan_device((void *)stream, nnz, side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>(),
+            schpf::build_tile_plan_device((void *)st, nnz, side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>(),
                                           side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>(), d_val.as<float>(),
                                           presorted, packed_ok, side == 0 ? N : G, side == 0 ? G : N,
                                           side == 0 ? sh_c : sh_g, td.host, &e, &eb, &s, &o);
@@ -659,8 +662,31 @@ template <typename T> struct Engine final : schpf_ctx {
             td.order_dev.release(); td.order_dev.p = o; td.order_dev.bytes = o ? (size_t)nnz * 4 : 0;
             td.order_identity = presorted;
             td.entry_slots = (int64_t)(eb / 4) / (td.host.packed ? 1 : 2);
-            finish_tile(td);
+        };
+        HIPCHK(hipStreamSynchronize(stream));   // the COO is on the device before either builder reads it
+        if (env_int("SCHPF_PLAN_THREADS", 2) >= 2) {
+            std::exception_ptr err;
+            std::thread helper([&] {
+                try {
+                    HIPCHK(hipSetDevice(device));
+                    hipStream_t st2 = nullptr;
+                    HIPCHK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+                    try {
+                        build_side(1, st2);
+                        HIPCHK(hipStreamSynchronize(st2));
+                    } catch (...) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); throw; }
+                    (void)hipStreamDestroy(st2);
+                } catch (...) { err = std::current_exception(); }
+            });
+            try { build_side(0, stream); } catch (...) { helper.join(); throw; }
+            helper.join();
+            if (err) std::rethrow_exception(err);
+        } else {
+            build_side(0, stream);
+            build_side(1, stream);
         }
+        finish_tile(tcell);
+        finish_tile(tgene);
         build_dual_order();
     }
 
