@@ -581,6 +581,9 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
     constexpr bool PAIR = KL * (int)sizeof(T) <= (MAXT <= 512 ? 192 : 96);
     constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
+    // wide rows: ONE row in registers, refilled vector by vector.  float64 only: the float32 kernel with wide rows
+    // (K = 50: 28 floats per lane) is 18 % slower with it (profiles/r03/ab_rolling_wide_rows.txt) and keeps the plain loop
+    constexpr bool ROLL = !PAIR && MODE != MODE_RANDOM && sizeof(T) == 8;
     T bA[KL], bB[KL];                                  // PIPE: the rows of the step being / about to be computed
     float xc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};         //       counts of that step [step parity][nonzero]
 
@@ -709,6 +712,70 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     if (p + I < steps) pipe_step(std::integral_constant<int, I>{});
                 SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
 #undef SCHPF_PIPE_STEP
+            }
+        } else if (ROLL) {
+            // Wide rows (two of them do not fit the registers beside the accumulators; K = 50 in f64: 14 doubles
+            // per lane): the pipeline of the paired loop with ONE row buffer.  The row of the next nonzero -- the
+            // step's second, or the next step's first -- is fetched into the buffer vector by vector, each 16-byte
+            // piece right behind the accumulation that read it last, so that its LDS latency runs under the rest of
+            // the accumulation instead of in front of the next dot product (the loop this replaces fetched a row,
+            // waited, and only then started).  As in the paired loop there is no test of the normaliser: an
+            // underflowed s poisons the group's accumulators (inf / NaN), which is detected once after the task.
+            typedef typename Vec16<T>::type V16;
+            unsigned second = 0;   // LDS position of the current step's second row
+            if (steps > 0) {       // prologue: the first step's first row (the ring was primed before the barrier)
+                const E c = ring[0];
+                unsigned i0 = EF::idx(c, 0);
+                second = EF::idx(c, 1);
+                xc[0][0] = EF::val(c, 0); xc[0][1] = EF::val(c, 1);
+                asm volatile("" : "+v"(i0), "+v"(second), "+v"(xc[0][0]), "+v"(xc[0][1]));
+                load_lane<T, NV, LPC>(lds_row<T>(lds_raw, i0), sub, bA);
+            }
+            // one nonzero: its weight from the row in the buffer, then the buffer becomes row `next`
+            auto roll_nonzero = [&](const T x, const unsigned next) {
+                const T s = group_dot<T, KL, LPC>(tm, bA);
+                const V16 *__restrict__ np = reinterpret_cast<const V16 *>(lds_row<T>(lds_raw, next)) + sub;
+                if (MODE == MODE_PHI) {
+                    const T q = fast_div(x, s);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[v * VEC + e] = fma_t(q, bA[v * VEC + e], acc[v * VEC + e]);
+                        Vec16<T>::unpack(np[v * LPC], &bA[v * VEC]);
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) Vec16<T>::unpack(np[v * LPC], &bA[v * VEC]);
+                    // lane 0 of the group keeps the group's share
+                    if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
+                }
+            };
+            auto roll_step = [&](auto I_) {
+                constexpr int I = decltype(I_)::value;
+                const E cn = ring[(I + 1) % RING];
+                unsigned n0 = EF::idx(cn, 0), n1 = EF::idx(cn, 1);
+                xc[(I + 1) & 1][0] = EF::val(cn, 0); xc[(I + 1) & 1][1] = EF::val(cn, 1);
+                asm volatile("" : "+v"(n0), "+v"(n1), "+v"(xc[(I + 1) & 1][0]), "+v"(xc[(I + 1) & 1][1]));
+                roll_nonzero((T)xc[I & 1][0], second);
+                __builtin_amdgcn_sched_barrier(0);
+                roll_nonzero((T)xc[I & 1][1], n0);
+                second = n1;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int p = 0;
+            for (; p + RING <= steps; p += RING) {
+#define SCHPF_ROLL_STEP(I)                                                           \
+    ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
+    roll_step(std::integral_constant<int, I>{});
+                SCHPF_ROLL_STEP(0) SCHPF_ROLL_STEP(1) SCHPF_ROLL_STEP(2) SCHPF_ROLL_STEP(3)
+#undef SCHPF_ROLL_STEP
+            }
+            if (p < steps) {
+#define SCHPF_ROLL_STEP(I)                                                           \
+    ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
+    if (p + I < steps) roll_step(std::integral_constant<int, I>{});
+                SCHPF_ROLL_STEP(0) SCHPF_ROLL_STEP(1) SCHPF_ROLL_STEP(2) SCHPF_ROLL_STEP(3)
+#undef SCHPF_ROLL_STEP
             }
         } else
         for (int p = 0; p < steps; p += RING) {
