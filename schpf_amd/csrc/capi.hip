@@ -1045,7 +1045,7 @@ template <typename T> struct Engine final : schpf_ctx {
         if (use_tile) {
             if (device_plans) build_tiles_device(row, col, v.data(), packed_ok, early);
             else build_tiles(row, col, v.data());
-            n_out = tcell.n_wave_out;
+            n_out = std::max(tcell.n_wave_out, tgene.n_wave_out);   // the loss pass sweeps either plan (loss_side)
         } else {
             const int wc = pick_windows((size_t)G * KP * sizeof(T), "SCHPF_WINDOWS_CELL");
             const int wg = pick_windows((size_t)N * KP * sizeof(T), "SCHPF_WINDOWS_GENE");
@@ -1435,8 +1435,10 @@ template <typename T> struct Engine final : schpf_ctx {
             throw std::logic_error("this engine holds gathered batch rows (schpf_upload_rows): evaluate the loss on the source");
         refresh_tables();
         ScopedTimer tm(prof, stream, 2);
-        run_sweep(0, schpf::MODE_LLH);
-        HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(), use_tile ? tcell.n_wave_out : cell.n_waves,
+        const int side = loss_side();
+        run_sweep(side, schpf::MODE_LLH);
+        HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(),
+                                         use_tile ? (side ? tgene.n_wave_out : tcell.n_wave_out) : cell.n_waves,
                                          scalars.as<double>(), stream));
         // explicitly stored zeros look like padding to the sweeps (weight 0, which is what they
         // contribute to the shape updates, hpf_numba.py:97-112), but the reference's loss counts
@@ -1451,6 +1453,19 @@ template <typename T> struct Engine final : schpf_ctx {
         *llh = n_zero > 0 ? h[0] - h[2] : h[0];
         *gl = gammaln_sum;
         *nnz_out = nnz;
+    }
+
+    // The loss pass sweeps ONE plan, either will do (both hold every nonzero; r = sum_k E[theta] E[beta] is symmetric).
+    // The cell-side plan unless it has too few tasks to fill the device and the gene-side plan has more: the task ranges
+    // are chosen for the iteration's merged launch, where C3 f64 gets one range per cell block = 196 tasks for 256
+    // compute units (loss pass 421 us on the cell plan; the gene plan's 640 tapered tasks: see DESIGN 9).
+    int loss_side() const
+    {
+        const int forced = env_int("SCHPF_LOSS_SIDE", -1);
+        if (forced == 0 || forced == 1) return use_tile ? forced : 0;
+        if (!use_tile || wave_out.bytes < (size_t)tgene.n_wave_out * sizeof(double)) return 0;
+        const int64_t resident = (int64_t)n_cu() * (tcell.lds_bytes > 80 * 1024 ? 1 : 2);
+        return (tcell.n_tasks < 2 * resident && tgene.n_tasks > tcell.n_tasks) ? 1 : 0;
     }
 
     void read_wave_out(double *out, int64_t n) override

@@ -832,6 +832,32 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
 
 
 @only_plans("tile", "half")
+@pytest.mark.parametrize("dtype,K", [(np.float64, 20), (np.float32, 20), (np.float64, 50)])
+def test_loss_is_the_same_on_either_plan(amd, oracle, plan_kind, monkeypatch, dtype, K):
+    """The loss pass sweeps ONE tile plan -- the cell-side one, or the gene-side one when the cell side has too few
+    tasks to fill the device (capi.hip loss_side): both hold every nonzero and r = sum_k E[theta] E[beta] is
+    symmetric, so the two must agree to summation order, with the oracle's loss (hpf_numba.py:24-51) and explicitly
+    stored zeros (counted by the reference's loss) included."""
+    from scipy.sparse import coo_matrix
+    X = synthetic_counts(1500, 900, 0.06, seed=23)
+    data = X.data.copy()
+    data[::11] = 0          # explicit zeros
+    X = coo_matrix((data, (X.row, X.col)), shape=X.shape)
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=9)
+    got = []
+    for side in ("0", "1"):
+        monkeypatch.setenv("SCHPF_LOSS_SIDE", side)
+        with load_engine(amd, X, K, dtype, st, 0.3, 0.3, bp, dp) as eng:
+            eng.step()
+            got.append(eng.mean_negative_pois_llh())
+            state = [eng.get_gamma(n) for n in ("theta", "beta")]
+    want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, state[0][0], state[0][1], state[1][0], state[1][1])
+    f32 = np.dtype(dtype) == np.float32
+    assert_allclose(got[0], got[1], rtol=1e-6 if f32 else 1e-12)
+    assert_allclose(got[0], want, rtol=1e-5 if f32 else 1e-10)
+
+
+@only_plans("tile", "half")
 @pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
 @pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True),
                                          (np.float64, 50, False)])
