@@ -668,7 +668,21 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 #pragma unroll
                         for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
                         step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
-                        // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated
+                        // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated.  The
+                        // scheduling barrier holds the machine scheduler; in the straight-line float32 turn the
+                        // optimiser had already hoisted B's accumulation above the loads (hipcc -S: the next dot
+                        // product then waited for rows requested a few instructions earlier), so there the order is
+                        // also pinned in the IR: the loads stay before a memory clobber, B's FMAs behind it
+                        if constexpr (sizeof(T) == 4 && KL % 2 == 0) {
+                            asm volatile("" ::: "memory");
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                            for (int k = 0; k < KL; k += 2) {   // in register pairs: the accumulation stays v_pk_fma_f32
+                                f32x2 t = {acc[k], acc[k + 1]};
+                                asm volatile("" : "+v"(t));
+                                acc[k] = t.x; acc[k + 1] = t.y;
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                         if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q1, bB[0], acc[0]); acc[1] = fma_t(q1, bB[KL - 1], acc[1]); } else
 #pragma unroll
