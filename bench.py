@@ -599,7 +599,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.init_phi_device(12345)          # t = 0 responsibilities (device generator)
+    # t = 0 responsibilities (device generator, keyed by (seed, LOCAL cell, gene)): every rank its own stream of it
+    eng.init_phi_device(12345 + 0x9E3779B97F4A7C15 * rank if world > 1 else 12345)
     for _ in range(args.warmup):
         step()
     many = getattr(drv, "steps", None) if sharded else eng.steps   # sharded: a graph only with SCHPF_GRAPH_SHARDED=1

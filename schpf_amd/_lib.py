@@ -73,6 +73,7 @@ STRING_FUNCS = ("schpf_last_error", "schpf_version")
 
 _lib = None
 HIP_RUNTIME = None
+IPC_NOTE = ""   # set by load() when dmabuf IPC may not be in effect (see there)
 
 
 class SchpfHipError(RuntimeError):
@@ -131,7 +132,19 @@ def load():
     # initialises, RCCL fails with `hipIpcGetMemHandle: invalid argument`.  Set here, ahead of the dlopen
     # below, so that fit(devices=[...]), run_trials_pool(devices=...), the CLI and bench.py all get it;
     # a value the caller exported wins.
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # It has to be set here and not on the multi-device paths only: the first HIP call of ANY engine initialises
+    # the runtime, and a later fit(devices=[...]) in the same process could no longer change it.  What this
+    # cannot fix is a runtime that was initialised before this module was loaded (torch.cuda touched first
+    # without the variable): IPC_NOTE records that, and comm_init failures quote it (ipc_hint()).
+    global IPC_NOTE
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") is None:
+        if _hsa_runtime_mapped():
+            IPC_NOTE = ("the HSA runtime was already loaded in this process without HSA_ENABLE_IPC_MODE_LEGACY=0 "
+                        "(e.g. torch.cuda was used before schpf_amd was imported): export it before starting Python")
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    elif os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] != "0":
+        IPC_NOTE = ("HSA_ENABLE_IPC_MODE_LEGACY=%s is exported; multi-GPU work on this driver stack needs 0"
+                    % os.environ["HSA_ENABLE_IPC_MODE_LEGACY"])
     HIP_RUNTIME = _hip_runtime_path()
     # RCCL follows the HIP runtime: the copy next to it (torch/lib or /opt/rocm/lib) unless overridden
     if not os.environ.get("SCHPF_RCCL_PATH"):
@@ -152,6 +165,19 @@ def load():
         getattr(lib, name).argtypes = []
     _lib = lib
     return lib
+
+
+def _hsa_runtime_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return "libhsa-runtime64" in f.read()
+    except OSError:
+        return False
+
+
+def ipc_hint():
+    """Appended to communicator errors: why device memory may not be shareable between ranks."""
+    return (" [" + IPC_NOTE + "]") if IPC_NOTE else ""
 
 
 def check(status):

@@ -369,6 +369,20 @@ template <typename T> struct Engine final : schpf_ctx {
         scalars.alloc(8 * sizeof(double), true, stream);
     }
     void hypers_changed() override { drop_graph(); }
+    // the engine holds no count matrix any more: plans, row copy and captured graphs released; step / loss calls
+    // raise until the next successful upload
+    void forget_matrix()
+    {
+        have_coo = false;
+        drop_graph();
+        HIPCHK(hipStreamSynchronize(stream));
+        cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
+        dual_order.release(); dual_slots = 0;
+        rows_ptr.release(); rows_col.release(); rows_val.release();
+        zero_row.release(); zero_col.release();
+        pending_init = 0;
+        eager_since_upload = false;
+    }
     void hint_sharded(int on) override { expect_sharded = on != 0; }
     void keep_rows(int on) override { want_rows = on != 0; }   // a, c, bp, dp are kernel arguments of the captured launches
     void drop_graph()
@@ -696,6 +710,7 @@ template <typename T> struct Engine final : schpf_ctx {
         Engine<T> *src = dynamic_cast<Engine<T> *>(source_);
         if (!src) throw std::invalid_argument("the source engine must have this engine's dtype");
         if (!src->rows_ptr.p || !src->have_coo) throw std::logic_error("the source keeps no rows (schpf_keep_rows before its upload)");
+        if (src == this) throw std::invalid_argument("an engine cannot gather batch rows from itself");
         if (src->device != device) throw std::invalid_argument("source and batch engine must be on one device");
         if (src->G != G || src->K != K) throw std::invalid_argument("source and batch engine differ in genes or factors");
         if (n_rows != N) throw std::invalid_argument("n_rows must be the number of cells the batch engine was created with");
@@ -706,6 +721,7 @@ template <typename T> struct Engine final : schpf_ctx {
             if (rows[i] < 0 || rows[i] >= src->N) throw std::invalid_argument("batch row out of range");
             dp[(size_t)i + 1] = dp[(size_t)i] + (sp[(size_t)rows[i] + 1] - sp[(size_t)rows[i]]);
         }
+        forget_matrix();                  // a failed plan build must not leave have_coo set over empty plans
         nnz = dp[(size_t)n_rows];
         std::vector<int32_t> rv(rows, rows + n_rows);
         DevBuf d_rows, d_dp, d_row, d_col, d_val;
@@ -716,7 +732,6 @@ template <typename T> struct Engine final : schpf_ctx {
                                          src->rows_val.as<float>(), d_dp.as<int64_t>(), d_row.as<int>(), d_col.as<int>(),
                                          d_val.as<float>(), stream));
         use_tile = true;
-        cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
         const int ranges[2] = {0, 0}, half[2] = {-1, -1};
         // rows in batch order with their columns ascending: sorted by (row, col) already
         plans_from_device_coo(d_row, d_col, d_val, true, false, src->rows_packed_ok, ranges, half);
@@ -974,6 +989,10 @@ template <typename T> struct Engine final : schpf_ctx {
         const double t_start = now_s();
         if (nnz_ < 0 || nnz_ >= (int64_t)1 << 31) throw std::invalid_argument("nnz must be < 2^31");
         if (kind < SCHPF_VAL_I32 || kind > SCHPF_VAL_F64) throw std::invalid_argument("unknown value kind");
+        // whatever the engine held is discarded on every path below: let go of it BEFORE anything new is allocated
+        // (a re-upload onto a live engine would otherwise peak at the old plans + the new indices), and an upload
+        // that fails leaves an engine without a matrix, not one with half of the old one
+        forget_matrix();
         EarlyIndexCopy early;
         const bool device_plans = want_tile && env_int("SCHPF_DEVICE_PLAN", 1);
         if (device_plans) early.start(device, nnz_, row, col);
@@ -1039,8 +1058,6 @@ template <typename T> struct Engine final : schpf_ctx {
         if (chunk < 2) chunk = 2;
         chunk &= ~1;
         use_tile = want_tile;
-        cell = PlanDev(); gene = PlanDev(); tcell = TileDev(); tgene = TileDev();
-        rows_ptr.release(); rows_col.release(); rows_val.release();   // kept again below, by the device-plan path only
         int64_t n_out;
         if (use_tile) {
             if (device_plans) build_tiles_device(row, col, v.data(), packed_ok, early);
@@ -1288,6 +1305,9 @@ template <typename T> struct Engine final : schpf_ctx {
     void init_phi_device(uint64_t seed) override
     {
         need_coo();
+        // a rank of a communicator numbers its cells from 0 like every other rank: without this, local cell i of
+        // every shard would draw the same responsibilities for a gene
+        if (comm && comm_world > 1) seed += 0x9E3779B97F4A7C15ull * (uint64_t)(comm_rank + 1);
         run_sweep(0, schpf::MODE_RANDOM, seed);
         run_sweep(1, schpf::MODE_RANDOM, seed);
         pending_init = 2;

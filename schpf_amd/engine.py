@@ -204,7 +204,10 @@ class DeviceCAVI(object):
         """Join the communicator (collective: returns once all `world` ranks have called it)."""
         if len(unique_id) != 128:
             raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
-        _lib.check(self._lib.schpf_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))
+        try:
+            _lib.check(self._lib.schpf_comm_init(self._h, ctypes.c_char_p(bytes(unique_id)), int(rank), int(world)))
+        except _lib.SchpfHipError as e:
+            raise _lib.SchpfHipError(str(e) + _lib.ipc_hint())
         self.comm_world = int(world)
 
     def steps_sharded(self, n, freeze_genes=False, simultaneous=False):

@@ -22,6 +22,7 @@ from scipy.sparse import coo_matrix
 from scipy.special import digamma, gammaln
 from sklearn.base import BaseEstimator
 
+from . import _lib
 from . import hpf_hip
 from . import loss as ls
 from ._version import __version__
@@ -330,8 +331,9 @@ class scHPF(BaseEstimator):
         (schpf_amd.sharded.ThreadedShards) and the result equals the single-GPU fit up to the
         summation order of those sums.
         `batchsize` (minibatch CAVI, scHPF_.py:626-650, 688-695) runs every iteration on the
-        device too, but re-uploads the batch's rows each iteration like the reference re-slices
-        them -- it exists for behavioural parity, not speed (nothing in HBM-sized data needs it).
+        device too: the matrix goes up once and each batch's rows are gathered in HBM
+        (_fit_minibatch); only when the whole matrix does not fit beside its plans are the
+        batch's rows sliced on the host and uploaded per iteration, like the reference re-slices.
         Returns (bp, dp, xi, eta, theta, beta, loss) like the reference.
         """
         assert loss_smoothing > 0
@@ -485,16 +487,43 @@ class scHPF(BaseEstimator):
             eng.set_hypers(a, c, bp, dp)
             eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
             eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
-            source = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
-            source.keep_rows()
-            source.upload(Xcsr.tocoo() if duplicates else X)
-            resident = source.upload_info()["rows"]     # False for host-built / gather plans: slice on the host then
-            whole = source
+            # The whole matrix on the device: as a row-sorted copy the batches are gathered from, and (default loss)
+            # as plans for the all-cells loss.  A matrix that does not fit HBM beside those falls back step by step:
+            # without the row copy (batches sliced on the host and uploaded, 8 B/nnz less) -- and with a caller's own
+            # loss function nothing of the whole matrix is needed on the device at all.
+            Xsum = Xcsr.tocoo() if duplicates else X
+
+            def whole_matrix_engine(M, keep):
+                e = DeviceCAVI(M.shape[0], M.shape[1], nfactors, dtype=dtype, device=device)
+                try:
+                    if keep:
+                        e.keep_rows()
+                    e.upload(M)
+                except _lib.SchpfHipError:
+                    e.close()
+                    return None
+                return stack.enter_context(e)
+
+            source = whole_matrix_engine(Xsum, True)
+            resident = source is not None and source.upload_info()["rows"]   # False for host-built / gather plans
+            whole = None
             if default_loss:
-                if duplicates:
-                    whole = stack.enter_context(DeviceCAVI(X.shape[0], X.shape[1], nfactors, dtype=dtype, device=device))
-                    whole.upload(X)
+                whole = source if not duplicates else None
+                if whole is None:
+                    whole = whole_matrix_engine(X, False)
+                if whole is None and source is not None and resident:
+                    # no room for both: give up the resident rows, keep the loss
+                    source.close()
+                    source, resident = None, False
+                    whole = whole_matrix_engine(X, False)
+                if whole is None:
+                    raise _lib.SchpfHipError("the count matrix does not fit this device's memory for the all-cells loss "
+                                             "(%s); pass a loss_function evaluated elsewhere or use more devices"
+                                             % _lib.load().schpf_last_error().decode("utf-8", "replace"))
                 whole.set_hypers(a, c, bp, dp)
+            if not resident and source is not None and source is not whole:
+                source.close()      # its plans serve nothing then
+                source = None
 
             def gene_side():      # eta.vi_shape is a constant of the model (:618); its rate and beta live on the device
                 if freeze_genes:

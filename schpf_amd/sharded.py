@@ -107,12 +107,6 @@ class ShardedCAVI(object):
         return -(llh - gl) / nnz
 
 
-# What ThreadedShards builds a shard's engine with when its caller passes nothing: None = DeviceCAVI.
-# A hook for the CPU test of the class (tests/test_sharded_cpu.py), not a fallback: the stand-in it
-# injects is test infrastructure.
-ENGINE_FACTORY = None
-
-
 class ThreadedShards(object):
     """One process, one host thread per GPU: the cells of X row-sharded over `devices`, every
     shard a DeviceCAVI on its device, all of them ranks of one RCCL communicator that lives
@@ -129,11 +123,11 @@ class ThreadedShards(object):
         """comm="rccl": the product path.  comm="emulated" (tests on a one-GPU box, where RCCL
         refuses two ranks on one device): no communicator; the all-reduce is played by adding the
         shards' exchange buffers through torch views -- same packing, same update kernels.
-        engine_factory: what builds a shard's engine (default DeviceCAVI; the CPU test of this
-        class injects a stand-in with the same surface, see ENGINE_FACTORY)."""
+        engine_factory: what builds a shard's engine (default DeviceCAVI; the CPU test of this class
+        passes a stand-in with the same surface and hands the finished object to fit(engine=...))."""
         from concurrent.futures import ThreadPoolExecutor
         from .engine import DeviceCAVI
-        make_engine = engine_factory or ENGINE_FACTORY or DeviceCAVI
+        make_engine = engine_factory or DeviceCAVI
         if not hasattr(X, "row"):
             X = X.tocoo()
         self.devices = list(devices)
@@ -163,7 +157,10 @@ class ThreadedShards(object):
             eng = make_engine(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
             try:
                 eng.hint_sharded()
-                eng.upload(sub)
+                try:
+                    eng.upload(sub, warn=False)    # a pool thread must not touch the warnings machinery
+                except TypeError:                  # stand-in engines of the CPU tests take no `warn`
+                    eng.upload(sub)
             except BaseException:
                 eng.close()
                 raise
@@ -191,6 +188,8 @@ class ThreadedShards(object):
         except BaseException:
             self.close()
             raise
+        if self.engines and hasattr(self.engines[0], "rounding_warning"):
+            self.engines[0].rounding_warning(stacklevel=3)   # once, on the calling thread
         if comm != "rccl":
             self._views = [e.exchange if hasattr(e, "exchange") else exchange_tensor_of(e, d)
                            for e, d in zip(self.engines, self.devices)]

@@ -108,8 +108,8 @@ def test_two_ranks_reproduce_the_unsharded_oracle(tmp_path, oracle, flags, dtype
 
 @pytest.mark.parametrize("kw", [{}, {"beta_theta_simultaneous": True}])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_fit_over_devices_through_the_estimator(oracle, monkeypatch, kw, dtype):
-    """scHPF.fit(X, devices=[0, 1]) end to end on CPU: the estimator's loop, ThreadedShards'
+def test_fit_over_devices_through_the_estimator(oracle, kw, dtype):
+    """scHPF.fit over two shards end to end on CPU (fit(X, devices=[0, 1]) builds the same ThreadedShards itself): the estimator's loop, ThreadedShards'
     partition / scatter / gather of the four Gammas, the per-stretch calls and the loss -- with
     oracle-backed stand-in engines in place of DeviceCAVI and the all-reduce summed on the host.
     Must reproduce the unsharded restatement of the reference's fit (same seed, same stop)."""
@@ -118,15 +118,14 @@ def test_fit_over_devices_through_the_estimator(oracle, monkeypatch, kw, dtype):
     from _oracle_engine import OracleShardEngine
     import schpf_amd.sharded as sharded
     from schpf import scHPF
-    monkeypatch.setattr(sharded, "ENGINE_FACTORY", OracleShardEngine)
-    monkeypatch.setenv("SCHPF_SHARD_COMM", "emulated")
     X = synthetic_counts(120, 90, 0.15, seed=9)
     K = 4
     np.random.seed(5)
     want = oracle.oracle_fit(X, K, dtype=dtype, max_iter=25, simultaneous=bool(kw))
     np.random.seed(5)
     model = scHPF(K, dtype=dtype, max_iter=25, verbose=False)
-    model.fit(X, devices=[0, 1], **kw)
+    with sharded.ThreadedShards(X, K, dtype, [0, 1], comm="emulated", engine_factory=OracleShardEngine) as shards:
+        model.fit(X, engine=shards, **kw)
     f32 = np.dtype(dtype) == np.float32
     assert model.bp == want["bp"] and model.dp == want["dp"]
     assert len(model.loss) == len(want["loss"])
