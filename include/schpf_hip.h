@@ -180,6 +180,10 @@ int schpf_synchronize(schpf_ctx *ctx);
  * sweeps then run as two launches, and the plans of a small row block are cut into tasks that fill the
  * GPU once per launch instead of once per pair of launches). */
 int schpf_hint_sharded(schpf_ctx *ctx, int on);
+/* Before schpf_upload_coo, optional: this context's matrix is replaced every iteration or so (the host-slicing
+ * fall-back of minibatch CAVI, scHPF_.py:643-650): plans are then built the cheapest way -- windows cut by index, no
+ * balancing pass (plan.h BALANCED WINDOWS pays for itself over tens of iterations on one matrix, not over one). */
+int schpf_hint_transient(schpf_ctx *ctx, int on);
 
 /* Minibatch CAVI without re-uploads (the reference re-slices X each iteration: X[batch_ix], scHPF_.py:643-650,
  * with util.minibatch_ix_generator :218-231).  schpf_keep_rows(ctx, 1) BEFORE schpf_upload_coo makes the engine

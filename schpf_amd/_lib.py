@@ -50,6 +50,7 @@ SIGNATURES = {
     "schpf_loss_terms": [_vp, _dblp, _dblp, _i64p],
     "schpf_synchronize": [_vp],
     "schpf_hint_sharded": [_vp, _int],
+    "schpf_hint_transient": [_vp, _int],
     "schpf_keep_rows": [_vp, _int],
     "schpf_upload_rows": [_vp, _vp, _vp, _int],
     "schpf_comm_unique_id": [_vp],

@@ -116,6 +116,8 @@ struct TileDev {
     schpf::TilePlanHost host;   // entries/steps cleared after upload; order/mptr kept
     DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, pfirst, pcount, partials;
     DevBuf task_order;          // tasks by decreasing work: the slot list of a persistent single-side launch
+    DevBuf minor_of;            // balanced windows (plan.h): [n_blocks * n_virtual] table row staged at a window position, or empty
+    int n_virtual = 0;
     DevBuf order_dev;           // device-built plans: (major, minor)-sorted position -> caller's COO position
     bool order_identity = false; //                    ... or the input was already in that order
     int64_t n_tasks = 0, entry_slots = 0, n_wave_out = 0;
@@ -222,6 +224,7 @@ struct schpf_ctx {
     virtual void steps(unsigned flags, int n) = 0;
     virtual void hypers_changed() = 0;
     virtual void hint_sharded(int on) = 0;
+    virtual void hint_transient(int on) = 0;
     virtual void keep_rows(int on) = 0;
     virtual void upload_rows(schpf_ctx *source, const int32_t *rows, int n_rows) = 0;
     virtual void steps_sharded(unsigned flags, int n) = 0;
@@ -304,6 +307,10 @@ template <typename T> struct Engine final : schpf_ctx {
     bool want_rows = false, rows_packed_ok = true;
     DevBuf rows_ptr, rows_col, rows_val;            // int64[N + 1], int32[nnz], float[nnz]; host copy of rows_ptr: tcell.host.mptr
     bool have_loss_constants = true;                // false after upload_rows (no lgamma sum / stored-zero list for a batch)
+    // balanced windows (plan.h): on for uploads of a whole matrix; off for an engine that keeps a (row, col)-sorted copy
+    // (the plans' own order is then the virtual one) and for batch engines, which re-plan every iteration
+    bool balance_now = false;
+    bool transient = false;             // schpf_hint_transient: the matrix is replaced every iteration, plan the cheapest way
     bool expect_sharded = false;        // schpf_hint_sharded: a rank of a sharded fit (gene-side sums leave for an all-reduce)
     static constexpr int UPD_BLOCKS = 2048;
     static constexpr size_t TABLE_PAD = 256 * 1024;
@@ -384,6 +391,7 @@ template <typename T> struct Engine final : schpf_ctx {
         eager_since_upload = false;
     }
     void hint_sharded(int on) override { expect_sharded = on != 0; }
+    void hint_transient(int on) override { transient = on != 0; }
     void keep_rows(int on) override { want_rows = on != 0; }   // a, c, bp, dp are kernel arguments of the captured launches
     void drop_graph()
     {
@@ -666,11 +674,32 @@ template <typename T> struct Engine final : schpf_ctx {
             TileDev &td = side == 0 ? tcell : tgene;
             void *e = nullptr, *s = nullptr, *o = nullptr;
             size_t eb = 0;
-            const bool presorted = side == 0 ? rc_sorted : cr_sorted;
-            schpf::build_tile_plan_device((void *)st, nnz, side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>(),
-                                          side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>(), d_val.as<float>(),
-                                          presorted, packed_ok, side == 0 ? N : G, side == 0 ? G : N,
-                                          side == 0 ? sh_c : sh_g, td.host, &e, &eb, &s, &o);
+            bool presorted = side == 0 ? rc_sorted : cr_sorted;
+            const int32_t *d_major = side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>();
+            const int32_t *d_minor = side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>();
+            const schpf::TileShape &sh = side == 0 ? sh_c : sh_g;
+            int n_minor_plan = side == 0 ? G : N;
+            DevBuf vminor;
+            td.minor_of.release(); td.n_virtual = 0;
+            if (balance_now && sh.ring <= 1 && sh.waves_per_block >= 12) {   // the balanced kernels are 1024-thread ones
+                const double tb = now_s();
+                vminor.alloc((size_t)nnz * 4);
+                schpf::BalanceGeometry geo;
+                void *mo = nullptr;
+                schpf::balance_windows_device((void *)st, nnz, d_major, d_minor, side == 0 ? N : G, n_minor_plan, sh,
+                                              vminor.as<int32_t>(), &mo, geo);
+                td.minor_of.p = mo; td.minor_of.bytes = (size_t)geo.n_blocks * geo.n_virtual * 4;
+                td.n_virtual = geo.n_virtual;
+                d_minor = vminor.as<int32_t>();
+                n_minor_plan = geo.n_virtual;
+                presorted = false;
+                if (env_int("SCHPF_VERBOSE", 0))
+                    fprintf(stderr, "[schpf_hip]   balanced windows, side %d: %d sections of %d windows, %.3f s\n", side,
+                            geo.n_sections, geo.D, now_s() - tb);
+            }
+            schpf::build_tile_plan_device((void *)st, nnz, d_major, d_minor, d_val.as<float>(),
+                                          presorted, packed_ok, side == 0 ? N : G, n_minor_plan,
+                                          sh, td.host, &e, &eb, &s, &o);
             td.entries.release(); td.entries.p = e; td.entries.bytes = eb;
             td.steps.release(); td.steps.p = s; td.steps.bytes = td.host.steps.size() * 2;
             td.order_dev.release(); td.order_dev.p = o; td.order_dev.bytes = o ? (size_t)nnz * 4 : 0;
@@ -722,6 +751,7 @@ template <typename T> struct Engine final : schpf_ctx {
             dp[(size_t)i + 1] = dp[(size_t)i] + (sp[(size_t)rows[i] + 1] - sp[(size_t)rows[i]]);
         }
         forget_matrix();                  // a failed plan build must not leave have_coo set over empty plans
+        balance_now = false;              // a batch is planned every iteration: the cheapest build
         nnz = dp[(size_t)n_rows];
         std::vector<int32_t> rv(rows, rows + n_rows);
         DevBuf d_rows, d_dp, d_row, d_col, d_val;
@@ -803,7 +833,7 @@ template <typename T> struct Engine final : schpf_ctx {
             blocks[s] = ((int64_t)n_maj[s] + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
             half_windows[s] = ((int64_t)n_min[s] + half_rows - 1) / half_rows;
             const double per_row = (double)nnz / std::max(1, n_maj[s]) * (double)half_rows / std::max(1, n_min[s]);
-            half_ok[s] = half_env != 0 && per_row >= 16.0;
+            half_ok[s] = half_env != 0 && per_row >= 16.0 && !balance_now;
             partial_seconds[s] = 2.0 * (double)n_maj[s] * (double)row_bytes / 3.5e12;
         }
         const int resident = n_cu();
@@ -820,7 +850,7 @@ template <typename T> struct Engine final : schpf_ctx {
         const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, share, (double)nnz, resident,
                                                                1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
                                                                partial_seconds,
-                                                               expect_sharded ? 4 : 6, 1.12, 32, expect_sharded,
+                                                               expect_sharded ? 4 : 6, balance_now ? 1.0 : 1.12, 32, expect_sharded,
                                                                env_int("SCHPF_TAPER", 30) / 100.0);
         if (c.ranges[0] <= 0 || c.ranges[1] <= 0) return false;
         for (int s = 0; s < 2; ++s) { ranges[s] = c.ranges[s]; half[s] = c.half[s] ? 1 : 0; }
@@ -874,7 +904,8 @@ template <typename T> struct Engine final : schpf_ctx {
         {
             const int half_env = env_int("SCHPF_HALF", -1);
             int n_slots = half_env >= 2 ? half_env : 0;
-            if (force_half >= 0) n_slots = force_half ? 2 : 0;
+            if (balance_now && half_env < 2) n_slots = 0;      // balanced windows are whole windows (plan.h)
+            else if (force_half >= 0) n_slots = force_half ? 2 : 0;
             else if (half_env < 0 && sh.ring <= 1 && wpb >= 12) {
                 const int64_t half_rows = ((int64_t)lds_kb * 512 - 64) / (int64_t)row_bytes;
                 if (half_rows >= 1) {
@@ -913,23 +944,44 @@ template <typename T> struct Engine final : schpf_ctx {
                                sh_g = tile_shape(G, N, true, ranges[1], half[1]);
         std::exception_ptr err;
         double secs_gene = 0.0;
+        // balanced windows: the builder runs on the block's virtual numbering of the minor rows (plan.h)
+        std::vector<int32_t> mo_cell, mo_gene;
+        auto build_host = [&](const int32_t *major, const int32_t *minor, int n_major, int n_minor, const schpf::TileShape &sh,
+                              TileDev &td, std::vector<int32_t> &mo) {
+            td.n_virtual = 0;
+            if (balance_now && sh.ring <= 1 && sh.waves_per_block >= 12) {
+                schpf::BigVec<int32_t> vminor;
+                schpf::BalanceGeometry geo;
+                schpf::balance_windows_host(nnz, major, minor, n_major, n_minor, sh, vminor, mo, geo);
+                td.n_virtual = geo.n_virtual;
+                schpf::build_tile_plan(nnz, major, vminor.data(), val, n_major, geo.n_virtual, sh, true, td.host);
+            } else {
+                schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, true, td.host);
+            }
+        };
         std::thread side([&] {
             try {
                 const double t0 = now_s();
-                schpf::build_tile_plan(nnz, col, row, val, G, N, sh_g, true, tgene.host);
+                build_host(col, row, G, N, sh_g, tgene, mo_gene);
                 secs_gene = now_s() - t0;
             } catch (...) { err = std::current_exception(); }
         });
         double secs_cell = 0.0;
         try {
             const double t0 = now_s();
-            schpf::build_tile_plan(nnz, row, col, val, N, G, sh_c, true, tcell.host);
+            build_host(row, col, N, G, sh_c, tcell, mo_cell);
             secs_cell = now_s() - t0;
         } catch (...) { side.join(); throw; }
         side.join();
         if (err) std::rethrow_exception(err);
         upload_tile(tcell, secs_cell);
         upload_tile(tgene, secs_gene);
+        tcell.minor_of.release(); tgene.minor_of.release();
+        mo_cell.resize(mo_cell.size() + 16, -1);   // a list is copied in 16-byte pieces: slack behind the last one
+        mo_gene.resize(mo_gene.size() + 16, -1);
+        if (tcell.n_virtual) upload(tcell.minor_of, mo_cell, stream);
+        if (tgene.n_virtual) upload(tgene.minor_of, mo_gene, stream);
+        HIPCHK(hipStreamSynchronize(stream));
         build_dual_order();
     }
 
@@ -939,7 +991,8 @@ template <typename T> struct Engine final : schpf_ctx {
         // plans agree on the workgroup shape: slots = all tasks of both plans, longest first
         dual_slots = 0;
         dual_order.release();
-        if (env_int("SCHPF_DUAL", 1) && tcell.threads == tgene.threads && tcell.packed == tgene.packed) {
+        if (env_int("SCHPF_DUAL", 1) && tcell.threads == tgene.threads && tcell.packed == tgene.packed &&
+            (tcell.n_virtual != 0) == (tgene.n_virtual != 0)) {
             const auto &hc = tcell.host, &hg = tgene.host;
             std::vector<int32_t> ord;
             const int n_xcd = env_int("SCHPF_XCD", 1);
@@ -993,6 +1046,19 @@ template <typename T> struct Engine final : schpf_ctx {
         // (a re-upload onto a live engine would otherwise peak at the old plans + the new indices), and an upload
         // that fails leaves an engine without a matrix, not one with half of the old one
         forget_matrix();
+        // Balanced windows where the rows are sparse in a window (on average under 24 nonzeros per row and 152 KiB window,
+        // both orientations: the C5 share has 7): there the lock-step padding is 45 % of the executed step slots and the
+        // balancing takes a quarter of the sweep's compute away; at C3 (49 per row and window) the half-window schedule
+        // already fills 0.87-0.93 of the slots and the row-list indirection of the staging costs what the rest would
+        // return (profiles/r04/ab_balanced_windows.txt).  SCHPF_BALANCE=1 / 0 forces it on / off.
+        {
+            const int forced = env_int("SCHPF_BALANCE", -1);
+            const double win = 152.0 * 1024.0 / ((double)KP * sizeof(T));
+            const double per_row_cell = (double)nnz_ / std::max(1, N) * std::min(1.0, win / std::max(1, G));
+            const double per_row_gene = (double)nnz_ / std::max(1, G) * std::min(1.0, win / std::max(1, N));
+            const bool sparse = per_row_cell < 24.0 && per_row_gene < 24.0 && (double)G > 2.0 * win && (double)N > 2.0 * win;
+            balance_now = (forced < 0 ? sparse : forced != 0) && want_tile && !want_rows && !transient;
+        }
         EarlyIndexCopy early;
         const bool device_plans = want_tile && env_int("SCHPF_DEVICE_PLAN", 1);
         if (device_plans) early.start(device, nnz_, row, col);
@@ -1211,7 +1277,9 @@ template <typename T> struct Engine final : schpf_ctx {
         a.log_minor = log_minor.as<T>();
         a.partials = td.partials.as<T>();
         a.wave_out = wave_out.as<double>();
-        a.K = K; a.n_minor = n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
+        a.K = K; a.n_minor = td.n_virtual ? td.n_virtual : n_minor; a.n_windows = td.host.n_windows; a.win_rows = td.host.win_rows;
+        a.minor_of = td.n_virtual ? td.minor_of.as<int>() : nullptr;
+        a.n_virtual = td.n_virtual;
         a.wpb = td.host.wpb;
         a.ring = td.host.ring; a.slot_bytes = td.host.slot16 * 16; a.sync_stage = td.host.sync_stage;
         return a;
@@ -1792,6 +1860,7 @@ int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int worl
 }
 int schpf_comm_destroy(schpf_ctx *ctx) { CTX_CALL(ctx->comm_destroy()); }
 int schpf_hint_sharded(schpf_ctx *ctx, int on) { CTX_CALL(ctx->hint_sharded(on)); }
+int schpf_hint_transient(schpf_ctx *ctx, int on) { CTX_CALL(ctx->hint_transient(on)); }
 int schpf_keep_rows(schpf_ctx *ctx, int on) { CTX_CALL(ctx->keep_rows(on)); }
 int schpf_upload_rows(schpf_ctx *ctx, schpf_ctx *source, const int32_t *rows, int n_rows)
 {
@@ -1940,6 +2009,16 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         sh.bank_order = env_int("SCHPF_BANK_ORDER", 2);
         sh.taper = env_int("SCHPF_TAPER", 0) / 100.0;
         if (sh.taper > 0.0) sh.slots = 1;   // tapered ranges are for orientations with more tasks than workgroups (plan.h)
+        // SCHPF_DEBUG_BALANCE=1: balanced windows (plan.h) -- the plan is built on the blocks' virtual numbering of the
+        // minor rows and every entry is mapped back through minor_of
+        std::vector<int32_t> minor_of;
+        schpf::BalanceGeometry geo;
+        const bool balanced = env_int("SCHPF_DEBUG_BALANCE", 0) != 0 && sh.ring <= 1;
+        if (balanced) {
+            schpf::BigVec<int32_t> vminor;
+            schpf::balance_windows_host(nnz, major, minor, n_major, n_minor, sh, vminor, minor_of, geo);
+            schpf::build_tile_plan(nnz, major, vminor.data(), val, n_major, geo.n_virtual, sh, false, P);
+        } else
         schpf::build_tile_plan(nnz, major, minor, val, n_major, n_minor, sh, false, P);
         const int W = P.n_windows, gpw = P.gpw, wpb = P.wpb, gpb = P.gpb;
         // the LDS model of plan.cpp::bank_order: the lane groups of a pass read one row each per half step; rows of
@@ -1991,7 +2070,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                                 if (n >= nnz) throw std::logic_error("tile plan stores more nonzeros than given");
                                 const int g = v * gpw + grp;
                                 out_major[n] = P.block_rows[(size_t)b * gpb + g];
-                                out_minor[n] = (int32_t)mn;
+                                out_minor[n] = balanced ? minor_of[(size_t)b * geo.n_virtual + (size_t)mn] : (int32_t)mn;
                                 out_val[n] = f;
                                 out_prow[n] = (int32_t)(t * gpb + g);
                                 out_task[n] = (int32_t)t;

@@ -39,6 +39,10 @@ template <typename T> struct TileArgs {
     T *partials;                   // [n_tasks * gpb, KP]
     double *wave_out;              // [n_tasks * wpb] (LLH)
     int K, n_minor, n_windows, win_rows, wpb;
+    // balanced windows (plan.h): block b stages window w from the table rows minor_of[b * n_virtual + w * win_rows + j]
+    // (-1: none); n_minor is then n_virtual.  nullptr: windows are index ranges of the table
+    const int *minor_of;
+    int n_virtual;
     int ring, slot_bytes;          // ring mode (plan.h): slots in the LDS ring (<= 1: window mode), bytes per slot
     int sync_stage;                // ring mode: half-window schedule (slots refilled at the epoch boundary)
     uint64_t seed;                 // MODE_RANDOM

@@ -1051,4 +1051,109 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     }
 }
 
+
+// ---- balanced windows (plan.h): the host reference; plan_device.hip balance_kernel follows the same rule
+// One (block, section): keys = the block's nonzeros of the section's minor rows as (minor << GROUP_BITS | group),
+// ascending.  virt_b / minor_of_b: this block's rows of the two tables.
+static void balance_section(const uint64_t *keys, int64_t n_keys, int m0, int m1, int w0, int Dn, int D, int win_rows,
+                            std::vector<uint16_t> &load, int32_t *virt_b, int32_t *minor_of_b)
+{
+    const uint64_t gmask = ((uint64_t)1 << BALANCE_GROUP_BITS) - 1;
+    std::fill(load.begin(), load.end(), (uint16_t)0);
+    int cnt[64] = {0};
+    for (int64_t i = 0; i < n_keys;) {
+        const int32_t m = (int32_t)(keys[i] >> BALANCE_GROUP_BITS);
+        int64_t e = i;
+        while (e < n_keys && (int32_t)(keys[e] >> BALANCE_GROUP_BITS) == m) ++e;
+        uint64_t best = ~(uint64_t)0;
+        for (int c = 0; c < Dn; ++c) {
+            if (cnt[c] >= win_rows) continue;
+            unsigned mx = 0, sm = 0;
+            for (int64_t q = i; q < e; ++q) {
+                const unsigned v = load[(size_t)(keys[q] & gmask) * D + c];
+                mx = std::max(mx, v);
+                sm += v;
+            }
+            best = std::min(best, balance_cost(mx, sm, (unsigned)c));
+        }
+        const int c = (int)(best & 0xff);
+        for (int64_t q = i; q < e; ++q) {
+            uint16_t &v = load[(size_t)(keys[q] & gmask) * D + c];
+            if (v < 65535) ++v;
+        }
+        const int32_t v = (w0 + c) * win_rows + cnt[c]++;
+        virt_b[m] = v;
+        minor_of_b[v] = m;
+        i = e;
+    }
+    // the minor rows no row of the block holds: the capacity left, window by window
+    int c = 0;
+    for (int32_t m = m0; m < m1; ++m) {
+        if (virt_b[m] >= 0) continue;
+        while (cnt[c] >= win_rows) ++c;
+        const int32_t v = (w0 + c) * win_rows + cnt[c]++;
+        virt_b[m] = v;
+        minor_of_b[v] = m;
+    }
+}
+
+void balance_windows_host(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
+                          const TileShape &shape, BigVec<int32_t> &vminor, std::vector<int32_t> &minor_of,
+                          BalanceGeometry &geo)
+{
+    if (shape.ring > 1) throw std::invalid_argument("balanced windows need whole windows (ring <= 1)");
+    // rows -> blocks exactly as the builder will cut them: that depends on the row lengths only
+    BigVec<int32_t> order;
+    std::vector<int64_t> mptr;
+    counting_sort_positions(nnz, major, n_major, order, mptr);
+    TilePlanHost T;
+    tile_plan_begin(T, nnz, n_major, n_minor, shape, mptr.data());
+    const int gpb = T.gpb, W = T.n_windows, win_rows = T.win_rows;
+    if (gpb > (1 << BALANCE_GROUP_BITS)) throw std::invalid_argument("balanced windows: more than 1024 rows per block");
+    geo = BalanceGeometry();
+    geo.gpb = gpb; geo.win_rows = win_rows; geo.n_windows = W; geo.n_blocks = T.n_blocks;
+    balance_sections(W, gpb, geo.n_sections, geo.D);
+    if ((int64_t)W * win_rows > 0x7fffffff) throw std::invalid_argument("balanced windows: virtual index overflow");
+    geo.n_virtual = W * win_rows;
+    const int D = geo.D, nsec = geo.n_sections;
+    vminor.resize((size_t)nnz);
+    minor_of.assign((size_t)T.n_blocks * geo.n_virtual, -1);
+    const int nth = host_threads();
+    parallel_for(T.n_blocks, nth, [&](int64_t b0, int64_t b1, int) {
+        std::vector<uint64_t> keys;
+        std::vector<int32_t> virt_b((size_t)n_minor);
+        std::vector<uint16_t> load((size_t)gpb * D);
+        for (int64_t b = b0; b < b1; ++b) {
+            keys.clear();
+            for (int g = 0; g < gpb; ++g) {
+                const int32_t row = T.block_rows[(size_t)b * gpb + g];
+                if (row < 0) continue;
+                for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j)
+                    keys.push_back(((uint64_t)(uint32_t)minor[order[(size_t)j]] << BALANCE_GROUP_BITS) | (uint64_t)g);
+            }
+            std::sort(keys.begin(), keys.end());
+            keys.erase(std::unique(keys.begin(), keys.end()), keys.end());   // a COO may hold an entry twice
+            std::fill(virt_b.begin(), virt_b.end(), -1);
+            int32_t *mo = minor_of.data() + (size_t)b * geo.n_virtual;
+            size_t lo = 0;
+            for (int s = 0; s < nsec; ++s) {
+                const int w0 = s * D, w1 = std::min(W, w0 + D);
+                const int m0 = w0 * win_rows, m1 = (int)std::min<int64_t>(n_minor, (int64_t)w1 * win_rows);
+                size_t hi = lo;
+                while (hi < keys.size() && (int64_t)(keys[hi] >> BALANCE_GROUP_BITS) < (int64_t)m1) ++hi;
+                balance_section(keys.data() + lo, (int64_t)(hi - lo), m0, m1, w0, w1 - w0, D, win_rows, load, virt_b.data(), mo);
+                lo = hi;
+            }
+            for (int g = 0; g < gpb; ++g) {
+                const int32_t row = T.block_rows[(size_t)b * gpb + g];
+                if (row < 0) continue;
+                for (int64_t j = mptr[row]; j < mptr[(size_t)row + 1]; ++j) {
+                    const int32_t pos = order[(size_t)j];
+                    vminor[(size_t)pos] = virt_b[(size_t)minor[pos]];
+                }
+            }
+        }
+    });
+}
+
 }  // namespace schpf

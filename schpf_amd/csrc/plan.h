@@ -22,6 +22,7 @@
 // natural ids of one major are consecutive (cptr), so the fused update kernel reduces
 // them in a fixed order: no atomics, run-to-run deterministic.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <sys/mman.h>
@@ -282,6 +283,56 @@ inline int tile_joint_pick(const Count *cnt, int stride, int n_classes, unsigned
     return (int)((wish + (15u - (key & 15u))) & (unsigned)(n_classes - 1));
 }
 void tile_plan_report(const TilePlanHost &P);
+
+// ---------------------------------------------------------------------------------------
+// BALANCED WINDOWS (round 4).  With windows cut by minor index, a row's nonzeros per window are Poisson
+// distributed and every (wave, window) lasts as long as its fullest row: 0.56 of the executed step slots
+// carry nonzeros at the C5 share (7 per row and window), 0.76 at C3 -- the padding executes every
+// instruction of a nonzero.  But WHICH minor rows share a window is free, per block: the window is
+// staged by LDS-DMA with one address per lane, so a window may be any `win_rows` rows of the table.
+// For every block the minor rows are therefore dealt to the windows greedily -- in minor order, each to
+// the window where the fullest of the block's rows that hold it stays lowest (ties: smallest sum of
+// those rows' loads, then the lowest window) -- inside SECTIONS of at most 32 consecutive windows (the
+// staging of a window then reads a bounded stretch of the table, and the sections are independent work
+// for the builders).  Minor rows no row of the block holds fill the capacity left, in order.  A
+// simulation of the rule gives 0.77-0.82 at the C5 share and 0.90-0.92 at C3 with WHOLE windows (the
+// half-window schedule reaches 0.87 there with twice the barriers).
+//
+// Expressed as a renumbering: block b sees minor row m as VIRTUAL row virt_b(m) = window * win_rows +
+// position; both builders run unchanged on the virtual indices (n_minor := n_virtual = n_windows *
+// win_rows) and the kernel stages window w of block b from the rows minor_of[b * n_virtual + w * win_rows
+// + j] (-1: no row).  Needs ring <= 1 (whole windows).
+struct BalanceGeometry {
+    int gpb = 0, win_rows = 0, n_windows = 0, n_sections = 0, D = 0;   // D windows per section (the last may have fewer)
+    int64_t n_blocks = 0;
+    int n_virtual = 0;
+};
+// windows per section: at most 32, and the builders' load matrix [gpb][D] of 16-bit counts within 60 KB
+inline void balance_sections(int n_windows, int gpb, int &n_sections, int &D)
+{
+    const int dmax = std::max(1, std::min(32, 30000 / std::max(gpb, 1)));
+    n_sections = std::max(1, (n_windows + dmax - 1) / dmax);
+    D = (n_windows + n_sections - 1) / n_sections;
+    n_sections = (n_windows + D - 1) / D;
+}
+// key of a nonzero for the balancing pass: (block, minor, lane group of its major row)
+constexpr int BALANCE_GROUP_BITS = 10;
+// cost of putting a minor row into a window: (fullest of its rows there, sum of its rows' loads, window)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t balance_cost(unsigned mx, unsigned sm, unsigned c)
+{
+    return ((uint64_t)mx << 40) | ((uint64_t)sm << 8) | (uint64_t)c;
+}
+// host builder: vminor[j] = virtual minor of nonzero j (caller's COO order), minor_of as above
+void balance_windows_host(int64_t nnz, const int32_t *major, const int32_t *minor, int n_major, int n_minor,
+                          const TileShape &shape, BigVec<int32_t> &vminor, std::vector<int32_t> &minor_of,
+                          BalanceGeometry &geo);
+// device builder (plan_device.hip): d_vminor [nnz] is written; *d_minor_of is allocated (hipMalloc, the caller frees)
+void balance_windows_device(void *stream, int64_t nnz, const int32_t *d_major, const int32_t *d_minor, int n_major,
+                            int n_minor, const TileShape &shape, int32_t *d_vminor, void **d_minor_of,
+                            BalanceGeometry &geo);
 
 // the (major, minor) / (minor, major) order of a host COO (one threaded scan)
 void coo_order_flags(int64_t nnz, const int32_t *major, const int32_t *minor, bool &sorted_major_minor,

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -570,6 +572,252 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         if (*out_steps) { (void)hipFree(*out_steps); *out_steps = nullptr; }
         throw;
     }
+}
+
+
+// ------------------------------------------------------------------ balanced windows (plan.h)
+namespace {
+
+__global__ void count_major_kernel(int64_t n, const int32_t *__restrict__ major, int32_t *__restrict__ count)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(count + major[j], 1);
+}
+// key = block << (minor_bits + GROUP_BITS) | minor << GROUP_BITS | lane group of the major row in its block
+__global__ void balance_keys_kernel(int64_t n, const int32_t *__restrict__ major, const int32_t *__restrict__ minor,
+                                    const int32_t *__restrict__ slot_of_row, int gpb, int minor_bits,
+                                    uint64_t *__restrict__ key)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t slot = slot_of_row[major[j]];
+        const uint64_t b = (uint64_t)(slot / gpb), g = (uint64_t)(slot % gpb);
+        key[j] = (b << (minor_bits + BALANCE_GROUP_BITS)) | ((uint64_t)(uint32_t)minor[j] << BALANCE_GROUP_BITS) | g;
+    }
+}
+__global__ void virtual_minor_kernel(int64_t n, const int32_t *__restrict__ major, const int32_t *__restrict__ minor,
+                                     const int32_t *__restrict__ slot_of_row, int gpb, int n_minor,
+                                     const int32_t *__restrict__ virt, int32_t *__restrict__ vminor)
+{
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = slot_of_row[major[j]] / gpb;
+        vminor[j] = virt[b * n_minor + minor[j]];
+    }
+}
+
+struct BalanceDev {
+    int gpb, win_rows, W, nsec, D, n_minor, n_virtual, minor_bits;
+};
+
+__device__ __forceinline__ int64_t lower_bound_key(const uint64_t *__restrict__ keys, int64_t n, uint64_t key)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t o = __shfl_xor(v, m, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// One wave per (block, section): plan.cpp balance_section with the candidate windows as lanes.  The minor
+// rows are taken in order (the greedy is sequential); the loads of a minor row's lane groups are read from the
+// LDS matrix eight at a time, every lane its own window's column.
+__global__ __launch_bounds__(64) void balance_kernel(BalanceDev g, const uint64_t *__restrict__ keys, int64_t n_keys,
+                                                     int32_t *__restrict__ virt, int32_t *__restrict__ minor_of)
+{
+    extern __shared__ uint16_t bal_lds[];
+    uint16_t *load = bal_lds;                       // [gpb][D]
+    uint16_t *glist = bal_lds + (size_t)g.gpb * g.D;   // the lane groups of the minor row at hand
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x / g.nsec;
+    const int s = blockIdx.x % g.nsec;
+    const int w0 = s * g.D, w1 = min(g.W, w0 + g.D), Dn = w1 - w0;
+    const int m0 = w0 * g.win_rows;
+    const int m1 = (int)min((int64_t)g.n_minor, (int64_t)w1 * g.win_rows);
+    for (int i = lane; i < g.gpb * g.D; i += 64) load[i] = 0;
+    const int shift = g.minor_bits + BALANCE_GROUP_BITS;
+    const int64_t lo = lower_bound_key(keys, n_keys, ((uint64_t)b << shift) | ((uint64_t)(uint32_t)m0 << BALANCE_GROUP_BITS));
+    const int64_t hi = lower_bound_key(keys, n_keys, ((uint64_t)b << shift) | ((uint64_t)(uint32_t)m1 << BALANCE_GROUP_BITS));
+    const uint32_t mmask = (uint32_t)(((uint64_t)1 << g.minor_bits) - 1);
+    const uint32_t gmask = (1u << BALANCE_GROUP_BITS) - 1u;
+    int my_cnt = 0;                                  // rows dealt to window w0 + lane so far
+    int32_t *virt_b = virt + b * g.n_minor;
+    int32_t *mo_b = minor_of + b * (int64_t)g.n_virtual;
+    __syncthreads();
+    int64_t pos = lo;
+    while (pos < hi) {
+        unsigned mx = 0, sm = 0;
+        int ng = 0;
+        int cur = -1;
+        for (;;) {                                   // the run of one minor row, 64 keys at a time
+            const bool in = pos + lane < hi;
+            const uint64_t k = in ? keys[pos + lane] : ~(uint64_t)0;
+            const uint32_t klo = (uint32_t)(k >> BALANCE_GROUP_BITS) & mmask;
+            if (cur < 0) cur = __builtin_amdgcn_readfirstlane((int)klo);
+            const uint64_t same = __ballot(in && (int)klo == cur);
+            const int run = same == ~(uint64_t)0 ? 64 : __builtin_ctzll(~same);
+            if (run == 0) break;
+            // a COO may hold an entry twice: equal keys are neighbours, only the first counts
+            const bool dup = in && pos + lane > lo && keys[pos + lane - 1] == k;
+            const uint64_t fresh = __ballot(lane < run && !dup);
+            const uint32_t grp = (uint32_t)k & gmask;
+            const int at = ng + __popcll(fresh & (((uint64_t)1 << lane) - 1));
+            if (((fresh >> lane) & 1) && at < g.gpb) glist[at] = (uint16_t)grp;
+            for (int i = 0; i < run; i += 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int src = min(i + u, run - 1);
+                    const uint32_t gi = (uint32_t)__builtin_amdgcn_readlane((int)grp, src);
+                    const bool on = i + u < run && ((fresh >> src) & 1);
+                    v[u] = (lane < Dn && on) ? (unsigned)load[(size_t)gi * g.D + lane] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { mx = max(mx, v[u]); sm += v[u]; }
+            }
+            ng += __popcll(fresh);
+            pos += run;
+            if (run < 64 || pos >= hi) break;
+        }
+        const uint64_t cost = (lane < Dn && my_cnt < g.win_rows) ? balance_cost(mx, sm, (unsigned)lane) : ~(uint64_t)0;
+        const int c = (int)(wave_min_u64(cost) & 0xff);
+        __syncthreads();                             // glist is written
+        for (int j = lane; j < min(ng, g.gpb); j += 64) {
+            uint16_t &v = load[(size_t)glist[j] * g.D + c];
+            if (v < 65535) ++v;
+        }
+        const int p = __builtin_amdgcn_readlane(my_cnt, c);
+        if (lane == c) ++my_cnt;
+        if (lane == 0) {
+            const int32_t v = (w0 + c) * g.win_rows + p;
+            virt_b[cur] = v;
+            mo_b[v] = cur;
+        }
+        __syncthreads();                             // the loads are up to date before the next row reads them
+    }
+    // the minor rows no row of the block holds fill the capacity left, window by window
+    __threadfence_block();
+    const int rem = lane < Dn ? g.win_rows - my_cnt : 0;
+    int pre = rem;                                   // inclusive prefix over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(pre, d, 64);
+        if (lane >= d) pre += o;
+    }
+    pre -= rem;                                      // exclusive
+    int ranked = 0;
+    for (int m = m0; m < m1; m += 64) {
+        const bool empty = m + lane < m1 && virt_b[m + lane] < 0;
+        const uint64_t bal = __ballot(empty);
+        const int rank = ranked + __popcll(bal & (((uint64_t)1 << lane) - 1));
+        int sel = -1, p = 0;
+        for (int c = 0; c < Dn; ++c) {
+            const int pc = __builtin_amdgcn_readlane(pre, c), rc = __builtin_amdgcn_readlane(rem, c);
+            const int cc = __builtin_amdgcn_readlane(my_cnt, c);
+            if (rank >= pc && rank < pc + rc) { sel = c; p = cc + rank - pc; }
+        }
+        if (empty && sel >= 0) {
+            const int32_t v = (w0 + sel) * g.win_rows + p;
+            virt_b[m + lane] = v;
+            mo_b[v] = m + lane;
+        }
+        ranked += __popcll(bal);
+    }
+}
+
+}  // namespace
+
+void balance_windows_device(void *stream, int64_t nnz, const int32_t *d_major, const int32_t *d_minor, int n_major,
+                            int n_minor, const TileShape &shape, int32_t *d_vminor, void **d_minor_of,
+                            BalanceGeometry &geo)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    *d_minor_of = nullptr;
+    if (shape.ring > 1) throw std::invalid_argument("balanced windows need whole windows (ring <= 1)");
+    const int threads = 256;
+    // row lengths -> the blocks the builder will cut (tile_plan_begin depends on the lengths only)
+    Tmp d_count((size_t)n_major * 4);
+    PD_CHECK(hipMemsetAsync(d_count.p, 0, (size_t)n_major * 4, st));
+    if (nnz > 0)
+        hipLaunchKernelGGL(count_major_kernel, dim3(grid_for(nnz, threads)), dim3(threads), 0, st, nnz, d_major,
+                           d_count.as<int32_t>());
+    std::vector<int32_t> count((size_t)n_major);
+    PD_CHECK(hipMemcpyAsync(count.data(), d_count.p, (size_t)n_major * 4, hipMemcpyDeviceToHost, st));
+    PD_CHECK(hipStreamSynchronize(st));
+    std::vector<int64_t> mptr((size_t)n_major + 1, 0);
+    for (int m = 0; m < n_major; ++m) mptr[(size_t)m + 1] = mptr[(size_t)m] + count[(size_t)m];
+    TilePlanHost T;
+    tile_plan_begin(T, nnz, n_major, n_minor, shape, mptr.data());
+    const int gpb = T.gpb, W = T.n_windows, win_rows = T.win_rows;
+    if (gpb > (1 << BALANCE_GROUP_BITS)) throw std::invalid_argument("balanced windows: more than 1024 rows per block");
+    if ((int64_t)W * win_rows > 0x7fffffff) throw std::invalid_argument("balanced windows: virtual index overflow");
+    geo = BalanceGeometry();
+    geo.gpb = gpb; geo.win_rows = win_rows; geo.n_windows = W; geo.n_blocks = T.n_blocks;
+    balance_sections(W, gpb, geo.n_sections, geo.D);
+    geo.n_virtual = W * win_rows;
+    std::vector<int32_t> slot_of_row((size_t)n_major, 0);
+    for (int64_t i = 0; i < T.n_blocks * gpb; ++i)
+        if (T.block_rows[(size_t)i] >= 0) slot_of_row[(size_t)T.block_rows[(size_t)i]] = (int32_t)i;
+    Tmp d_slot((size_t)n_major * 4);
+    PD_CHECK(hipMemcpyAsync(d_slot.p, slot_of_row.data(), (size_t)n_major * 4, hipMemcpyHostToDevice, st));
+
+    int minor_bits = 1, block_bits = 1;
+    while (((int64_t)1 << minor_bits) < (int64_t)std::max(n_minor, 1)) ++minor_bits;
+    while (((int64_t)1 << block_bits) < std::max<int64_t>(T.n_blocks, 1)) ++block_bits;
+    const int end_bit = BALANCE_GROUP_BITS + minor_bits + block_bits;
+    if (end_bit > 64) throw std::invalid_argument("balanced windows: key overflow");
+    Tmp virt((size_t)T.n_blocks * n_minor * 4);
+    void *mo = nullptr;
+    PD_CHECK(hipMalloc(&mo, (size_t)T.n_blocks * geo.n_virtual * 4 + 64));   // + slack: a list is copied in 16-byte pieces
+    try {
+        PD_CHECK(hipMemsetAsync(virt.p, 0xFF, (size_t)T.n_blocks * n_minor * 4, st));
+        PD_CHECK(hipMemsetAsync(mo, 0xFF, (size_t)T.n_blocks * geo.n_virtual * 4 + 64, st));
+        Tmp k_in((size_t)nnz * 8), k_out((size_t)nnz * 8);
+        if (nnz > 0) {
+            hipLaunchKernelGGL(balance_keys_kernel, dim3(grid_for(nnz, threads)), dim3(threads), 0, st, nnz, d_major, d_minor,
+                               d_slot.as<int32_t>(), gpb, minor_bits, k_in.as<uint64_t>());
+            size_t temp_bytes = 0;
+            PD_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (int)nnz,
+                                                       0, end_bit, st));
+            Tmp temp(temp_bytes);
+            PD_CHECK(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (int)nnz,
+                                                       0, end_bit, st));
+            PD_CHECK(hipStreamSynchronize(st));   // temp dies here
+        }
+        const bool verbose = getenv("SCHPF_VERBOSE") && atoi(getenv("SCHPF_VERBOSE"));
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_sorted = now();
+        BalanceDev bd{gpb, win_rows, W, geo.n_sections, geo.D, n_minor, geo.n_virtual, minor_bits};
+        const size_t lds = ((size_t)gpb * geo.D + (size_t)gpb) * 2;
+        const int64_t units = T.n_blocks * geo.n_sections;
+        if (units > 0x7fffffff) throw std::invalid_argument("balanced windows: too many (block, section) units");
+        if (units > 0)
+            hipLaunchKernelGGL(balance_kernel, dim3((unsigned)units), dim3(64), lds, st, bd, k_out.as<uint64_t>(), nnz,
+                               virt.as<int32_t>(), static_cast<int32_t *>(mo));
+        if (verbose) {
+            PD_CHECK(hipStreamSynchronize(st));
+            fprintf(stderr, "[schpf_hip]     balance: %lld (block, section) units dealt in %.4f s (keys sorted before that)\n",
+                    (long long)units, now() - t_sorted);
+        }
+        if (nnz > 0)
+            hipLaunchKernelGGL(virtual_minor_kernel, dim3(grid_for(nnz, threads)), dim3(threads), 0, st, nnz, d_major, d_minor,
+                               d_slot.as<int32_t>(), gpb, n_minor, virt.as<int32_t>(), d_vminor);
+        PD_CHECK(hipGetLastError());
+        PD_CHECK(hipStreamSynchronize(st));
+    } catch (...) {
+        (void)hipFree(mo);
+        throw;
+    }
+    *d_minor_of = mo;
 }
 
 }  // namespace schpf

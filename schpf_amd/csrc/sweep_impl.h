@@ -277,7 +277,7 @@ template <typename T, int NV, int LPC, bool PACK>
 __device__ __noinline__ void slow_task_row(const void *__restrict__ entries, size_t pos, const uint16_t *__restrict__ st,
                                            int w0, int w1, int win_rows, int ring, int slot16, int stride,
                                            const T *__restrict__ lt_row, const T *__restrict__ log_minor, int sub,
-                                           int K, T *__restrict__ out_row)
+                                           int K, T *__restrict__ out_row, const int *__restrict__ minor_of_block)
 {
     typedef TileEntry<PACK> EF;
     constexpr int KL = NV * Vec16<T>::N;
@@ -296,7 +296,8 @@ __device__ __noinline__ void slow_task_row(const void *__restrict__ entries, siz
             for (int u = 0; u < 2; ++u) {
                 const float x = EF::val(ee, u);
                 if (x > 0.f) {
-                    const int minor = entry_minor(EF::idx(ee, u), w, win_rows, ROW_SLOTS, ring, slot16);
+                    int minor = entry_minor(EF::idx(ee, u), w, win_rows, ROW_SLOTS, ring, slot16);
+                    if (minor_of_block) minor = minor_of_block[minor];   // balanced windows: virtual -> table row
                     slow_nonzero<T, NV, LPC>(lt_row, log_minor + (size_t)minor * KP, sub, K, (T)x, acc);
                 }
             }
@@ -551,7 +552,9 @@ template <typename T> __device__ __forceinline__ const T *lds_row(const unsigned
     return reinterpret_cast<const T *>(lds + (off16 << 4));
 }
 
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
+// BAL: balanced windows (plan.h) -- an instantiation of its own (1024-thread workgroups only), so that the row-list
+// staging costs the kernels of index-cut windows neither registers nor instructions
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
 __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, const int task)
 {
     typedef TileEntry<PACK> EF;
@@ -604,6 +607,39 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     auto stage = [&](int sw, int slot) {
         const int r0 = sw * a.win_rows;
         const int nr = min(a.win_rows, a.n_minor - r0);
+        if constexpr (BAL) {
+            // balanced windows (plan.h): the window is a LIST of table rows.  A wave instruction copies RPI whole rows
+            // (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS side of the DMA is base + 16 * lane,
+            // so rows land back to back); the row numbers of a batch of instructions are fetched first, then the copies
+            // go out.  Measured alternatives (profiles/r04/ab_balanced_windows.txt): row numbers fetched before the
+            // barrier (registers the step loop does not have: 177 spilled, 3 x slower) and row lists staged through LDS
+            // (the compiler drains the copies in front of every later LDS read; slower than this)
+            constexpr int ROW_SLOTS = KP * (int)sizeof(T) / 16;
+            constexpr int RPI = 64 / ROW_SLOTS;
+            constexpr int BATCH = 6;
+            const int rr = lane / ROW_SLOTS, q = lane - rr * ROW_SLOTS;
+            const int *__restrict__ list = a.minor_of + (size_t)blk * a.n_virtual + r0;
+            unsigned char *dst = lds_raw + (size_t)slot * a.slot_bytes;
+            const unsigned char *__restrict__ tab = reinterpret_cast<const unsigned char *>(a.tab_minor);
+            const int n_inst = (nr + RPI - 1) / RPI;
+            for (int i0 = wv; i0 < n_inst; i0 += BATCH * a.wpb) {   // scalar loop
+                int row[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int j = (i0 + u * a.wpb) * RPI + rr;
+                    row[u] = (rr < RPI && j < nr) ? list[j] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int i = i0 + u * a.wpb;
+                    if (i < n_inst && row[u] >= 0)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(tab + ((size_t)row[u] * ROW_SLOTS + q) * 16),
+                            (__attribute__((address_space(3))) void *)(dst + (size_t)i * RPI * ROW_SLOTS * 16), 16, 0, 0);
+                }
+            }
+            return;
+        }
         const unsigned char *__restrict__ src = reinterpret_cast<const unsigned char *>(a.tab_minor + (size_t)r0 * KP);
         unsigned char *dst = lds_raw + (size_t)slot * a.slot_bytes;
         const int nbytes = nr * KP * (int)sizeof(T);                  // a multiple of 16
@@ -807,7 +843,8 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                         // t = 0 responsibilities (reference scHPF_.py:652-655), counter-based draws
 #pragma unroll 1
                         for (int u = 0; u < 2; ++u) {
-                            const unsigned minor = (unsigned)entry_minor(u ? i1 : i0, w, a.win_rows, KP * (int)sizeof(T) / 16, a.ring, a.slot_bytes / 16);
+                            unsigned minor = (unsigned)entry_minor(u ? i1 : i0, w, a.win_rows, KP * (int)sizeof(T) / 16, a.ring, a.slot_bytes / 16);
+                            if (a.minor_of) minor = (unsigned)a.minor_of[(size_t)blk * a.n_virtual + minor];
                             const double x = (double)(u ? xf1 : xf0);
                             if (!(x > 0.0)) continue;
                             const uint64_t cell = a.major_is_cell ? (uint64_t)major : (uint64_t)minor;
@@ -878,7 +915,8 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     if (MODE == MODE_PHI && __builtin_expect(any_bad && live, 0)) {   // group-uniform; rare: see slow_nonzero
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
                                         a.win_rows, a.ring, a.slot_bytes / 16, GPW, a.log_major + (size_t)major * KP,
-                                        a.log_minor, sub, a.K, out_row);
+                                        a.log_minor, sub, a.K, out_row,
+                                        BAL ? a.minor_of + (size_t)blk * a.n_virtual : nullptr);
         return;
     }
     if (MODE == MODE_PHI) {
@@ -890,22 +928,22 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 }
 
 
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
-    tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK>(a, task);
+    tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK, BAL>(a, task);
 }
 
 // launch slot -> task: longest tasks first (plan.h task_order), so the launch has a short tail
 // a.queue: persistent workgroups, as in tile_sweep_dual_kernel below
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
 __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
     __shared__ int next_slot;
     int slot = blockIdx.x;
     for (;;) {
         const int task = a.task_order ? a.task_order[slot] : slot;
-        tile_sweep_task<T, NV, LPC, MODE, MAXT, PACK>(a, task);
+        tile_sweep_task<T, NV, LPC, MODE, MAXT, PACK, BAL>(a, task);
         if (MODE == MODE_RANDOM || !a.queue) return;
         __syncthreads();
         if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&a.queue[0], 1);
@@ -929,7 +967,7 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 // longest-first list is balanced by who is free, not by the dispatcher's round-robin.  queue[1]
 // counts the workgroups that have found the list empty; the last one zeroes both words for the
 // next launch.
-template <typename T, int NV, int LPC, int MAXT, bool PACK>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
 __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
                                                               const int *__restrict__ order, int n_slots,
                                                               int *__restrict__ queue)
@@ -941,8 +979,8 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, T
 #endif
     for (;;) {
         const int code = order[slot];
-        if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a0, code);
-        else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK>(a1, ~code);
+        if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>(a0, code);
+        else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>(a1, ~code);
         if (!queue) return;
         __syncthreads();                                   // the window and next_slot are free again
         if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&queue[0], 1);
@@ -970,7 +1008,7 @@ static inline bool lds_opt_in_pending(std::atomic<uint64_t> &raised)
     return (raised.fetch_or(bit) & bit) == 0;
 }
 
-template <typename T, int NV, int LPC, int MAXT, bool PACK>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
 static hipError_t launch_tile_b(const TileArgs<T> &a_in, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
 {
@@ -982,18 +1020,18 @@ static hipError_t launch_tile_b(const TileArgs<T> &a_in, int mode, int64_t n_tas
         static std::atomic<uint64_t> raised{0};
         if (lds_opt_in_pending(raised)) {
             // not the full 160 KiB: the kernels have a static word of LDS of their own (next_slot)
-            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>,
+            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>,
+                e = hipFuncSetAttribute((const void *)tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK, BAL>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
             if (e != hipSuccess) { raised = 0; return e; }
         }
     }
     if (mode == MODE_PHI)
-        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK>), grid, block, lds_bytes, st, a);
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>), grid, block, lds_bytes, st, a);
     else if (mode == MODE_LLH)
-        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK>), grid, block, lds_bytes, st, a);
+        hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_LLH, MAXT, PACK, BAL>), grid, block, lds_bytes, st, a);
     else   // one-off: the 1024-thread bound serves every workgroup size (one instantiation instead of two)
         hipLaunchKernelGGL((tile_sweep_kernel<T, NV, LPC, MODE_RANDOM, 1024, PACK>), grid, block, 0, st, a);
     return hipGetLastError();
@@ -1007,11 +1045,14 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
     if (threads <= 512)
         return packed ? launch_tile_b<T, NV, LPC, 512, true>(a, mode, n_tasks, threads, lds_bytes, st)
                       : launch_tile_b<T, NV, LPC, 512, false>(a, mode, n_tasks, threads, lds_bytes, st);
+    if (a.minor_of && mode != MODE_RANDOM)   // balanced windows: capi.hip builds them for 1024-thread workgroups only
+        return packed ? launch_tile_b<T, NV, LPC, 1024, true, true>(a, mode, n_tasks, threads, lds_bytes, st)
+                      : launch_tile_b<T, NV, LPC, 1024, false, true>(a, mode, n_tasks, threads, lds_bytes, st);
     return packed ? launch_tile_b<T, NV, LPC, 1024, true>(a, mode, n_tasks, threads, lds_bytes, st)
                   : launch_tile_b<T, NV, LPC, 1024, false>(a, mode, n_tasks, threads, lds_bytes, st);
 }
 
-template <typename T, int NV, int LPC, int MAXT, bool PACK>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
 static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
                                 int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
 {
@@ -1019,14 +1060,14 @@ static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, co
         static std::atomic<uint64_t> raised{0};
         if (lds_opt_in_pending(raised)) {
             // not the full 160 KiB: the kernel has a static word of LDS of its own (next_slot)
-            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>,
+            hipError_t e = hipFuncSetAttribute((const void *)tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK, BAL>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
             if (e != hipSuccess) { raised = 0; return e; }
         }
     }
     if (queue && resident >= n_slots) queue = nullptr;   // one round: nothing to draw
     const unsigned grid = queue ? (unsigned)resident : (unsigned)n_slots;
-    hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK>), dim3(grid), dim3((unsigned)threads), lds_bytes,
+    hipLaunchKernelGGL((tile_sweep_dual_kernel<T, NV, LPC, MAXT, PACK, BAL>), dim3(grid), dim3((unsigned)threads), lds_bytes,
                        st, a0, a1, order, (int)n_slots, queue);
     return hipGetLastError();
 }
@@ -1039,6 +1080,10 @@ static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, co
     if (threads <= 512)
         return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
                       : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
+    if ((a0.minor_of != nullptr) != (a1.minor_of != nullptr)) return hipErrorInvalidValue;   // both plans balanced, or neither
+    if (a0.minor_of)
+        return packed ? launch_dual_b<T, NV, LPC, 1024, true, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                      : launch_dual_b<T, NV, LPC, 1024, false, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
                   : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
 }

@@ -200,6 +200,11 @@ class DeviceCAVI(object):
         """Call before upload() when the engine will run sharded iterations (two sweep launches)."""
         _lib.check(self._lib.schpf_hint_sharded(self._h, int(bool(on))))
 
+    def hint_transient(self, on=True):
+        """Call before upload() when the engine's matrix will be replaced every iteration (minibatches sliced on the
+        host): its plans are then built the cheapest way (no balancing pass)."""
+        _lib.check(self._lib.schpf_hint_transient(self._h, int(bool(on))))
+
     def comm_init(self, unique_id, rank, world):
         """Join the communicator (collective: returns once all `world` ranks have called it)."""
         if len(unique_id) != 128:

@@ -484,6 +484,7 @@ class scHPF(BaseEstimator):
         from contextlib import ExitStack
         with ExitStack() as stack:
             eng = stack.enter_context(DeviceCAVI(batchsize, X.shape[1], nfactors, dtype=dtype, device=device))
+            eng.hint_transient()          # a new batch every iteration: plans built the cheapest way
             eng.set_hypers(a, c, bp, dp)
             eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
             eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)

@@ -189,6 +189,58 @@ def test_joint_bank_order_has_the_fewest_modelled_conflicts(lpc, row_slots, ring
     assert extra[2] < 0.8 * extra[1] < 0.8 * extra[0], extra
 
 
+@pytest.mark.parametrize("lpc,wpb,win_rows,tasks", [(4, 8, 64, 64), (2, 4, 37, 1), (1, 1, 1000, 7), (8, 2, 5, 1000), (1, 16, 11, 16)])
+@pytest.mark.parametrize("coo_order", ["shuffled", "row-major", "duplicates"])
+def test_balanced_windows_roundtrip(lpc, wpb, win_rows, tasks, coo_order, monkeypatch):
+    """Balanced windows (plan.h): every block deals the minor rows to its windows itself and the plan is built on that
+    virtual numbering.  Through the block's row list every nonzero must come back exactly once, in a partial row of its
+    major, and a virtual row must belong to one window of its section only."""
+    monkeypatch.setenv("SCHPF_DEBUG_BALANCE", "1")
+    X = synthetic_counts(257, 1031, 0.04, seed=5)
+    row, col, val = X.row, X.col, X.data.astype(np.float32)
+    if coo_order == "shuffled":
+        perm = np.random.RandomState(0).permutation(X.nnz)
+        row, col, val = row[perm], col[perm], val[perm]
+    if coo_order == "duplicates":      # a COO may hold an entry twice (the reference sums them when it converts)
+        row = np.concatenate([row, row[:500]]); col = np.concatenate([col, col[:500]]); val = np.concatenate([val, val[:500] + 1])
+    for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
+        om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, tasks)
+        n_tasks, n_blocks, n_windows, pstride = st[:4]
+        key_in = major.astype(np.int64) * nm + minor
+        key_out = om.astype(np.int64) * nm + on
+        oi = np.lexsort((val, key_in)); oo = np.lexsort((ov, key_out))
+        assert np.array_equal(key_in[oi], key_out[oo])
+        assert np.array_equal(val[oi], ov[oo])
+        j = (oprow - pfirst[om]) // pstride
+        assert np.array_equal(pfirst[om] + j * pstride, oprow)
+        assert np.all(j >= 0) and np.all(j < pcount[om])
+        assert n_windows == -(-nm // win_rows)
+
+
+def test_balanced_windows_store_fewer_slots(monkeypatch):
+    """The point of the balancing: at the C5 share's shape (7 nonzeros per row and window, 16 rows per wave) the
+    lock-step padding shrinks -- the stored step slots fall by more than a fifth -- and at C3's shape (seven windows
+    here: one section) whole balanced windows store about what the half-window schedule stores, with half the barriers."""
+    monkeypatch.setenv("SCHPF_DEBUG_ROW_SLOTS", "28")
+    X = synthetic_counts(2048, 4000, 0.02, seed=3)
+    v = X.data.astype(np.float32)
+    slots = {}
+    for bal in ("0", "1"):
+        monkeypatch.setenv("SCHPF_DEBUG_BALANCE", bal)
+        slots[bal] = sum(expand_tile(M, m, v, nM, nm, 4, 16, 347, 1)[-1][4]
+                         for M, m, nM, nm in ((X.row, X.col, 2048, 4000), (X.col, X.row, 4000, 2048)))
+    assert slots["1"] < 0.8 * slots["0"], slots
+    monkeypatch.setenv("SCHPF_DEBUG_ROW_SLOTS", "10")
+    X = synthetic_counts(2048, 6000, 0.05, seed=4)
+    v = X.data.astype(np.float32)
+    monkeypatch.setenv("SCHPF_DEBUG_BALANCE", "0")
+    half = expand_tile(X.row, X.col, v, 2048, 6000, 2, 16, 0, 1, -2, 77824)[-1][4]
+    whole = expand_tile(X.row, X.col, v, 2048, 6000, 2, 16, 972, 1)[-1][4]
+    monkeypatch.setenv("SCHPF_DEBUG_BALANCE", "1")
+    balanced = expand_tile(X.row, X.col, v, 2048, 6000, 2, 16, 972, 1)[-1][4]
+    assert balanced < 0.87 * whole and balanced < 1.05 * half, (balanced, half, whole)
+
+
 def test_tile_plan_tiny():
     om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile([3], [2], [7.0], 6, 5, 4, 8, 64, 2048)
     assert (om[0], on[0], ov[0]) == (3, 2, 7.0) and st[0] == 1 and pcount[3] == 1

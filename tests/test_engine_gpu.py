@@ -17,17 +17,23 @@ from conftest import load_golden, golden_coo, synthetic_counts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["tile", "half", "gather"])
+@pytest.fixture(autouse=True, params=["tile", "half", "gather", "balanced"])
 def plan_kind(request, monkeypatch):
     """Every engine test runs on all sweep implementations: the LDS-staged tile plan with the
     schedule the library picks ("tile", what ships), with the half-window schedule forced ("half":
-    SCHPF_HALF=2), and the L2-gather plan (selected by the library from SCHPF_PLAN at upload time).
-    A test that belongs to some of them narrows the list with `only_plans(...)` -- no ids that can
-    only skip."""
-    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param == "half" else request.param)
+    SCHPF_HALF=2), with balanced windows forced ("balanced": SCHPF_BALANCE=1 -- the library itself only
+    balances sparse, wide problems like the C5 share), and the L2-gather plan (selected by the library
+    from SCHPF_PLAN at upload time).  A test that belongs to some of them narrows the list with
+    `only_plans(...)` -- no ids that can only skip."""
+    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param in ("half", "balanced") else request.param)
     monkeypatch.delenv("SCHPF_HALF", raising=False)
+    monkeypatch.delenv("SCHPF_BALANCE", raising=False)
     if request.param == "half":
         monkeypatch.setenv("SCHPF_HALF", "2")
+    monkeypatch.delenv("SCHPF_WPB", raising=False)
+    if request.param == "balanced":
+        monkeypatch.setenv("SCHPF_BALANCE", "1")
+        monkeypatch.setenv("SCHPF_WPB", "16")     # the balanced kernels are the 1024-thread ones
     return request.param
 
 
@@ -375,7 +381,7 @@ def test_xcd_launch_order_changes_nothing_but_the_order(amd, oracle, plan_kind, 
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
-@only_plans("tile", "half")
+@only_plans("tile", "half", "balanced")
 def test_persistent_dual_launch_equals_one_workgroup_per_task_bitwise(amd, oracle, plan_kind, monkeypatch):
     """The dual sweep launch as persistent workgroups that draw tasks from a device counter (default)
     against one workgroup per task (SCHPF_PERSISTENT=0), with more tasks than the device holds at once so
@@ -638,6 +644,7 @@ def test_rows_gathered_on_the_device_equal_a_host_slice(amd, oracle, plan_kind, 
     with amd.DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype) as source, \
             amd.DeviceCAVI(nb, X.shape[1], K, dtype=dtype) as dev, amd.DeviceCAVI(nb, X.shape[1], K, dtype=dtype) as host:
         source.keep_rows()
+        host.hint_transient()          # like scHPF._fit_minibatch: a batch engine plans the cheap way, by either route
         source.upload(X)
         assert source.upload_info()["rows"]
         for eng in (dev, host):
@@ -810,7 +817,7 @@ def test_skewed_expression_matrix_matches_oracle(amd, oracle):
             assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-10)
 
 
-@only_plans("tile", "half")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, monkeypatch):
     """One launch for both orientations (tile_sweep_dual_kernel) runs the same tasks with the same
@@ -831,7 +838,7 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
             assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
 
 
-@only_plans("tile", "half")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype,K", [(np.float64, 20), (np.float32, 20), (np.float64, 50)])
 def test_loss_is_the_same_on_either_plan(amd, oracle, plan_kind, monkeypatch, dtype, K):
     """The loss pass sweeps ONE tile plan -- the cell-side one, or the gene-side one when the cell side has too few
@@ -857,7 +864,7 @@ def test_loss_is_the_same_on_either_plan(amd, oracle, plan_kind, monkeypatch, dt
     assert_allclose(got[0], want, rtol=1e-5 if f32 else 1e-10)
 
 
-@only_plans("tile", "half")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
 @pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True),
                                          (np.float64, 50, False)])
@@ -1010,7 +1017,7 @@ def test_library_rccl_one_rank_equals_plain_steps(amd, oracle, hinted):
         assert_allclose(shard.mean_negative_pois_llh(), want, rtol=1e-11)
 
 
-@only_plans("tile", "half")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("graph", ["0", "1"])
 def test_sharded_stretches_with_mode_switches_match_oracle(amd, oracle, plan_kind, dtype, graph, monkeypatch):

@@ -23,7 +23,7 @@ def run(X, K, setting, steps=10):
     kv = dict(item.split("=") for item in setting.split(",") if item)
     dtype = np.float32 if kv.pop("dtype", "f64") == "f32" else np.float64
     for k in list(os.environ):
-        if k.startswith("SCHPF_"):
+        if k.startswith("SCHPF_") and k != "SCHPF_VERBOSE":
             del os.environ[k]
     for k, v in kv.items():
         os.environ[k] = v
