@@ -604,18 +604,56 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     // asynchronous global -> LDS copy (global_load_lds_dwordx4): a wave instruction moves 1 KiB (LDS
     // address = wave-uniform base + 16 * lane), no staging registers and every piece in flight at
     // once; the __syncthreads that follows drains them (vmcnt(0)) first
+    // balanced windows (plan.h, BAL): the window is a LIST of table rows.  Wave wv copies the window's rows
+    // [wv * RPW, (wv + 1) * RPW); their numbers are fetched one window AHEAD, a lane each (one or two registers that
+    // live through the step loop), and handed to the copying lanes by ds_bpermute -- no load in front of the copies
+    constexpr int ROW_SLOTS = KP * (int)sizeof(T) / 16;
+    constexpr int RPI = 64 / ROW_SLOTS;     // whole rows per copy instruction
+    const int rpw = BAL ? (a.win_rows + a.wpb - 1) / a.wpb : 0;
+    const bool rows_ahead = BAL && rpw <= 128;
+    int rows_lo = -1, rows_hi = -1;
+    auto fetch_rows = [&](int sw) {
+        if (!rows_ahead) return;
+        const int r0 = sw * a.win_rows;
+        const int nr = min(a.win_rows, a.n_minor - r0);
+        const int *__restrict__ list = a.minor_of + (size_t)blk * a.n_virtual + r0;
+        const int l = wv * rpw + lane;
+        rows_lo = (lane < rpw && l < nr) ? list[l] : -1;
+        rows_hi = (lane + 64 < rpw && l + 64 < nr) ? list[l + 64] : -1;
+    };
+    if (BAL && MODE != MODE_RANDOM) fetch_rows(w0);
     auto stage = [&](int sw, int slot) {
         const int r0 = sw * a.win_rows;
         const int nr = min(a.win_rows, a.n_minor - r0);
+        if (BAL && rows_ahead) {
+            // a wave instruction copies RPI whole rows (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS
+            // side of the DMA is base + 16 * lane, so rows land back to back)
+            const int rr = lane / ROW_SLOTS, q = lane - rr * ROW_SLOTS;
+            unsigned char *dst = lds_raw + (size_t)slot * a.slot_bytes + (size_t)wv * rpw * ROW_SLOTS * 16;
+            const unsigned char *__restrict__ tab = reinterpret_cast<const unsigned char *>(a.tab_minor);
+            const int n_u = (rpw + RPI - 1) / RPI;
+            for (int u = 0; u < n_u; ++u) {   // scalar loop
+                const int src = u * RPI + rr;                      // the lane's row among the wave's
+                int row = __builtin_amdgcn_ds_bpermute((src & 63) << 2, rows_lo);
+                if (rpw > 64) {
+                    const int hi = __builtin_amdgcn_ds_bpermute((src & 63) << 2, rows_hi);
+                    row = src < 64 ? row : hi;
+                }
+                if (rr < RPI && src < rpw && row >= 0)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(tab + ((size_t)row * ROW_SLOTS + q) * 16),
+                        (__attribute__((address_space(3))) void *)(dst + (size_t)u * RPI * ROW_SLOTS * 16), 16, 0, 0);
+            }
+            return;
+        }
         if constexpr (BAL) {
-            // balanced windows (plan.h): the window is a LIST of table rows.  A wave instruction copies RPI whole rows
+            // (very narrow rows: more than 128 rows per wave) the row numbers of a batch of copy instructions are
+            // fetched in the staging itself, then the copies go out.  A wave instruction copies RPI whole rows
             // (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS side of the DMA is base + 16 * lane,
             // so rows land back to back); the row numbers of a batch of instructions are fetched first, then the copies
             // go out.  Measured alternatives (profiles/r04/ab_balanced_windows.txt): row numbers fetched before the
             // barrier (registers the step loop does not have: 177 spilled, 3 x slower) and row lists staged through LDS
             // (the compiler drains the copies in front of every later LDS read; slower than this)
-            constexpr int ROW_SLOTS = KP * (int)sizeof(T) / 16;
-            constexpr int RPI = 64 / ROW_SLOTS;
             constexpr int BATCH = 6;
             const int rr = lane / ROW_SLOTS, q = lane - rr * ROW_SLOTS;
             const int *__restrict__ list = a.minor_of + (size_t)blk * a.n_virtual + r0;
@@ -662,6 +700,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             if (SCHPF_ABLATE != 3 || w == w0)
             for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
+            if (BAL && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
         }
         if (PIPE) {
             // Rolling LDS pipeline, one nonzero deep: the minor rows of step p+1 are fetched from the
