@@ -43,6 +43,7 @@ template <typename T> struct TileArgs {
     // (-1: none); n_minor is then n_virtual.  nullptr: windows are index ranges of the table
     const int *minor_of;
     int n_virtual;
+    int llh_tab_off;               // MODE_LLH: byte offset in LDS of the logarithm table (behind the window; LlhAccumulator::TABLE_BYTES)
     int ring, slot_bytes;          // ring mode (plan.h): slots in the LDS ring (<= 1: window mode), bytes per slot
     int sync_stage;                // ring mode: half-window schedule (slots refilled at the epoch boundary)
     uint64_t seed;                 // MODE_RANDOM

@@ -495,37 +495,45 @@ template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
 // The entry stream runs through a 4-slot register ring: slot i is refilled with step p+4 as
 // soon as step p has been taken out of it, and the ring for the NEXT window is primed before
 // that window's staging barrier, so HBM latency hides behind four steps of math or a staging.
-// sum over nonzeros of x * log(r) - r without a log per nonzero: log(prod r^x) with the product
-// kept as mantissa x 2^exponent.  r^x for counts up to 15 is three squarings and conditional
-// multiplies; larger counts (rare in UMI data) take the log.  One f64 log costs ~80 VALU
-// instructions, this ~25; the rounding error of the running product (one ulp per multiply, a few
-// thousand multiplies per lane) is ~1e-13 absolute on a per-lane sum of order 1e3.
+// sum over nonzeros of x * log(r) - r with a TABLE-DRIVEN logarithm: r = m 2^e (v_frexp), the top six mantissa bits
+// pick c_i = (64.5 + i) / 128 from a 64-entry table {log c_i, 1 / c_i} in LDS, t = m / c_i - 1 is within 2^-7 and
+// log(1 + t) is seven terms of its series (the eighth is below 2e-18): ~20 VALU instructions and one ds_read_b128 per
+// nonzero, good to ~2e-16 absolute, for any count x.  History: a libm log per nonzero was ~80 instructions (round 1);
+// log(prod r^x) with the product kept as mantissa x 2^exponent ~45 (round 2, counts up to 15 only).  The loss pass
+// went 0.46 -> see profiles/r04 at C3.
 struct LlhAccumulator {
-    double mant = 1.0, rare = 0.0, rsum = 0.0;
-    int expo = 0;
-    __device__ __forceinline__ void add(double x, double r)
+    double sum = 0.0, rsum = 0.0;
+    static constexpr int TABLE_BYTES = 64 * 16;
+    // 64 threads of the workgroup fill the table (every task: ~100 instructions); a barrier follows before its first use
+    static __device__ __forceinline__ void fill_table(double2 *tab, int tid)
+    {
+        if (tid < 64) {
+            const double c = (64.5 + (double)tid) * (1.0 / 128.0);
+            tab[tid] = make_double2(log(c), 1.0 / c);
+        }
+    }
+    __device__ __forceinline__ void add(double x, double r, const double2 *tab)
     {
         rsum += r;
-        const int xi = (int)x;
-        if (xi > 15 || (double)xi != x) { rare += x * log(r); return; }   // divergent, rare
+        if (!(r >= 2.3e-308 && r <= 1.7e308)) { sum += x * log(r); return; }   // zero, denormal, inf, NaN: divergent, rare
         const int e = __builtin_amdgcn_frexp_exp(r);
-        const double m = __builtin_amdgcn_frexp_mant(r);                    // [0.5, 1), or 0 / inf / nan as r
-        expo += xi * e;
-        double p = (xi & 1) ? m : 1.0;
-        const double m2 = m * m;
-        p = (xi & 2) ? p * m2 : p;
-        const double m4 = m2 * m2;
-        p = (xi & 4) ? p * m4 : p;
-        const double m8 = m4 * m4;
-        p = (xi & 8) ? p * m8 : p;
-        const double q = mant * p;                                           // >= 2^-16: no underflow
-        expo += __builtin_amdgcn_frexp_exp(q);
-        mant = __builtin_amdgcn_frexp_mant(q);
+        const double m = __builtin_amdgcn_frexp_mant(r);                          // [0.5, 1)
+        const int i = (__double2hiint(m) >> 14) & 63;                             // top six mantissa bits
+        const double2 c = tab[i];
+        const double t = fma(m, c.y, -1.0);
+        double p = 1.0 / 7.0;
+        p = fma(p, t, -1.0 / 6.0);
+        p = fma(p, t, 1.0 / 5.0);
+        p = fma(p, t, -1.0 / 4.0);
+        p = fma(p, t, 1.0 / 3.0);
+        p = fma(p, t, -1.0 / 2.0);
+        p = fma(p * t, t, t);                                                     // log(1 + t)
+        const double ed = (double)e;
+        double lg = fma(ed, 0.693147180559945286, c.x);                           // ln 2 = hi + lo
+        lg = fma(ed, 2.319046813846299558e-17, lg) + p;
+        sum = fma(x, lg, sum);
     }
-    __device__ __forceinline__ double total() const
-    {
-        return (double)expo * 0.69314718055994530942 + log(mant) + rare - rsum;
-    }
+    __device__ __forceinline__ double total() const { return sum - rsum; }
 };
 
 // Ablation switches of development builds (tools/devbuild.sh, DEVFLAGS=-DSCHPF_ABLATE=n; timing
@@ -580,8 +588,13 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     if (MODE != MODE_RANDOM && live) load_lane<T, NV, LPC>(a.tab_major + (size_t)major * KP, sub, tm);
     double llh = 0.0;
     LlhAccumulator lacc;   // MODE_LLH
+    // ... and its logarithm table, behind the window in LDS (a.llh_tab_off; the window loop's first barrier publishes it)
+    const double2 *llh_tab = reinterpret_cast<const double2 *>(lds_raw + (MODE == MODE_LLH ? a.llh_tab_off : 0));
+    if (MODE == MODE_LLH) LlhAccumulator::fill_table(reinterpret_cast<double2 *>(lds_raw + a.llh_tab_off), (int)threadIdx.x);
     bool any_bad = false;
     // narrow rows: two minor rows in registers (a 512-thread workgroup has twice the registers per lane)
+    // (the loss pass keeps no accumulators, but pairing its wide rows -- K = 50: 112 bytes per lane -- spills 25-34
+    // registers into the step loop: loss evaluation at the C5 share 1.30 -> 1.64 ms in f64, 0.49 -> 0.55 in f32; round 4)
     constexpr bool PAIR = KL * (int)sizeof(T) <= (MAXT <= 512 ? 192 : 96);
     constexpr bool PIPE = PAIR && MODE != MODE_RANDOM;
     // wide rows: ONE row in registers, refilled vector by vector.  float64 only: the float32 kernel with wide rows
@@ -769,14 +782,14 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                     }
                     if (MODE == MODE_LLH) {
                         if (LPC == 1) {
-                            if (x0 > T(0)) lacc.add((double)x0, (double)s0);
-                            if (x1 > T(0)) lacc.add((double)x1, (double)s1);
+                            if (x0 > T(0)) lacc.add((double)x0, (double)s0, llh_tab);
+                            if (x1 > T(0)) lacc.add((double)x1, (double)s1, llh_tab);
                         } else {
                             // every lane of the group knows s0 and s1: lane 0 takes the first
                             // nonzero, lane 1 the second
                             const T sm = (sub & 1) ? s1 : s0;
                             const T xm = (sub & 1) ? x1 : x0;
-                            if (sub < 2 && xm > T(0)) lacc.add((double)xm, (double)sm);
+                            if (sub < 2 && xm > T(0)) lacc.add((double)xm, (double)sm, llh_tab);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -836,7 +849,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 #pragma unroll
                     for (int v = 0; v < NV; ++v) Vec16<T>::unpack(np[v * LPC], &bA[v * VEC]);
                     // lane 0 of the group keeps the group's share
-                    if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
+                    if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s, llh_tab);
                 }
             };
             auto roll_step = [&](auto I_) {
@@ -918,7 +931,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                                 for (int k = 0; k < KL; ++k) acc[k] = fma_t(q, b[k], acc[k]);
                             } else {
                                 // lane 0 of the group keeps the group's share
-                                if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s);
+                                if ((LPC == 1 || sub == 0) && x > T(0)) lacc.add((double)x, (double)s, llh_tab);
                             }
                         }
                     }

@@ -17,14 +17,15 @@ from conftest import load_golden, golden_coo, synthetic_counts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["tile", "half", "gather", "balanced"])
+@pytest.fixture(autouse=True, params=["tile", "half", "gather"])
 def plan_kind(request, monkeypatch):
     """Every engine test runs on all sweep implementations: the LDS-staged tile plan with the
     schedule the library picks ("tile", what ships), with the half-window schedule forced ("half":
     SCHPF_HALF=2), with balanced windows forced ("balanced": SCHPF_BALANCE=1 -- the library itself only
     balances sparse, wide problems like the C5 share), and the L2-gather plan (selected by the library
     from SCHPF_PLAN at upload time).  A test that belongs to some of them narrows the list with
-    `only_plans(...)` -- no ids that can only skip."""
+    `only_plans(...)` -- no ids that can only skip -- and the tests of the iteration itself add "balanced"
+    (`every_plan`)."""
     monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param in ("half", "balanced") else request.param)
     monkeypatch.delenv("SCHPF_HALF", raising=False)
     monkeypatch.delenv("SCHPF_BALANCE", raising=False)
@@ -39,6 +40,9 @@ def plan_kind(request, monkeypatch):
 
 def only_plans(*kinds):
     return pytest.mark.parametrize("plan_kind", list(kinds), indirect=True)
+
+
+every_plan = only_plans("tile", "half", "gather", "balanced")
 
 
 @pytest.fixture(scope="module")
@@ -85,10 +89,11 @@ CASES = [  # (ncells, ngenes, density, K)
 ]
 
 
+@every_plan
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
-def test_iterations_match_oracle(amd, oracle, dtype, case, flags):
+def test_iterations_match_oracle(amd, oracle, dtype, case, flags, plan_kind):
     N, G, dens, K = case
     X = synthetic_counts(N, G, dens, seed=N + K)
     a, c = 0.3, 0.3
@@ -134,8 +139,9 @@ def _fuzz_matrix(rng):
     return coo_matrix((X.data[order], (X.row[order], X.col[order])), shape=(N, G)), K
 
 
+@every_plan
 @pytest.mark.parametrize("seed", range(24))
-def test_random_problems_match_oracle(amd, oracle, seed):
+def test_random_problems_match_oracle(amd, oracle, seed, plan_kind):
     """Seeded fuzz over shapes (1 x 1 upwards, off-by-one around the 64-lane and window sizes), K from 1 to
     100, fill 0.5-40 %, heavy-tailed rows and columns, counts beyond 16 bits, shuffled COO order, both
     dtypes and every ordering flag (1 x n matrices are left out: the reference's bp = mean / var of the row sums
@@ -159,8 +165,9 @@ def test_random_problems_match_oracle(amd, oracle, seed):
         assert_allclose(loss, want, rtol=2e-5 if f32 else 1e-11)
 
 
+@every_plan
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_random_phi_first_iteration_matches_oracle(amd, oracle, dtype):
+def test_random_phi_first_iteration_matches_oracle(amd, oracle, dtype, plan_kind):
     """t == 0: responsibilities drawn on the host (reference scHPF_.py:652-655)."""
     X = synthetic_counts(300, 500, 0.05, seed=3)
     K, a, c = 6, 0.3, 0.3
@@ -193,7 +200,8 @@ def test_device_random_phi_is_a_valid_start(amd, oracle):
     assert np.all(ths > a * 0.999) and np.all(bes >= c)
 
 
-def test_underflow_fallback_matches_log_domain_oracle(amd, oracle):
+@every_plan
+def test_underflow_fallback_matches_log_domain_oracle(amd, oracle, plan_kind):
     """Factors whose E[log] differ by thousands make the product form underflow; the
     kernel must fall back to the reference's max-shifted form (hpf_numba.py:98-112)."""
     X = synthetic_counts(120, 150, 0.15, seed=21)
@@ -213,7 +221,8 @@ def test_underflow_fallback_matches_log_domain_oracle(amd, oracle):
         compare_state(eng, st, rtol=1e-10)
 
 
-def test_empty_rows_and_columns_keep_the_prior(amd, oracle):
+@every_plan
+def test_empty_rows_and_columns_keep_the_prior(amd, oracle, plan_kind):
     """The reference's own test matrix has 77 all-zero genes; shapes stay at the prior."""
     g = load_golden("pbmc_like_data.npz")
     X = golden_coo(g)
@@ -242,8 +251,9 @@ FITS = [
 ]
 
 
+@every_plan
 @pytest.mark.parametrize("fname,dtype,kw", FITS)
-def test_fit_reproduces_reference_trace(amd, fname, dtype, kw):
+def test_fit_reproduces_reference_trace(amd, fname, dtype, kw, plan_kind):
     """scHPF.fit() from the reference's seed reproduces the reference's run: same bp/dp,
     same number of loss checks (same stop decision), same losses, same final model."""
     from schpf import scHPF
@@ -423,8 +433,9 @@ def test_engine_argument_errors(amd):
             eng.set_gamma("theta", np.ones((50, 2)), np.ones((50, 2)))
 
 
+@every_plan
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_real_valued_data_and_stored_zeros_match_oracle(amd, oracle, dtype):
+def test_real_valued_data_and_stored_zeros_match_oracle(amd, oracle, dtype, plan_kind):
     """The reference fits any non-negative X.data (normalised / down-weighted counts, explicitly
     stored zeros, counts beyond 2^24; hpf_numba.py:98-112 only multiplies by it).  Values travel
     as float32 (a RuntimeWarning says so when that rounds); a stored zero adds nothing to the
@@ -782,7 +793,8 @@ def test_rccl_all_reduce_accepts_the_exchange_buffer(amd, oracle, stream_kind):
         dist.destroy_process_group()
 
 
-def test_skewed_expression_matrix_matches_oracle(amd, oracle):
+@every_plan
+def test_skewed_expression_matrix_matches_oracle(amd, oracle, plan_kind):
     """Real count matrices are heavy-tailed: a few genes are seen in almost every cell, most in
     a handful, and cell depths vary several-fold.  Zipf-distributed gene popularity, log-normal
     depths, a few all-zero cells and genes, counts up to the thousands (and one above 65535, which
@@ -902,6 +914,7 @@ def test_device_plan_equals_host_plan(amd, oracle, plan_kind, monkeypatch, coo_o
         assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
 
 
+@every_plan
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
 def test_steps_call_equals_single_steps_bitwise(amd, oracle, dtype, flags, plan_kind):
