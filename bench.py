@@ -488,7 +488,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prewarm-s", type=float, default=0.3,
-                    help="seconds of untimed iterations before the warm-up steps (GPU clock ramp; 0 = none)")
+                    help="seconds of loss evaluations (read-only sweeps) before the warm-up steps (GPU clock ramp; 0 = none)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -606,21 +606,19 @@ def main():
     # Device warm-up, untimed and outside the W warm-up steps: a fresh process reaches the timed region after seconds of
     # host-side work (matrix generation, plan build) with the GPU in a low power state, and a 15 ms timed region (the
     # driver's --steps 20) then measures the clock ramp -- round 3: 0.77 ms per iteration there against 0.70 in a
-    # 100-step run of the same build on the same box class.  Iterations until --prewarm-s of wall-clock have passed.
-    prewarm_iters = 0
+    # 100-step run of the same build on the same box class.  The warm-up work is LOSS EVALUATIONS (the same sweep
+    # kernel in its read-only mode): they do not advance the model, so the W warm-up steps and the K timed steps still
+    # start from the t = 0 state and `loss_after_warmup` / `loss_after_steps` still show the fit moving.
+    prewarm_evals = 0
     if args.prewarm_s > 0 and world > 1:
-        # ranks must issue the same number of collectives: a fixed count instead of a clock
-        prewarm_iters = 300
-        for _ in range(prewarm_iters):
-            step()
-        fence()
+        prewarm_evals = 200          # ranks must issue the same number of collectives: a count, not a clock
+        for _ in range(prewarm_evals):
+            loss_fn()
     elif args.prewarm_s > 0:
         t_pw = time.perf_counter()
         while time.perf_counter() - t_pw < args.prewarm_s:
-            for _ in range(10):
-                step()
-            fence()
-            prewarm_iters += 10
+            loss_fn()
+            prewarm_evals += 1
     for _ in range(args.warmup):
         step()
     many = getattr(drv, "steps", None) if sharded else eng.steps   # sharded: a graph only with SCHPF_GRAPH_SHARDED=1
@@ -692,8 +690,8 @@ def main():
             "launch": ("one library call for the %d timed iterations (%s), after %d untimed iterations of the same call"
                        % (args.steps, "schpf_steps_sharded; a hipGraph with one rank or SCHPF_GRAPH_SHARDED=1" if sharded
                           else "schpf_steps: one hipGraph replay", args.steps)
-                       + "; before the %d warm-up steps %d untimed iterations (%.1f s) bring the GPU out of its idle clocks"
-                       % (args.warmup, prewarm_iters, args.prewarm_s))
+                       + "; before the %d warm-up steps %d loss evaluations (read-only sweeps, %.1f s) bring the GPU out of its idle clocks"
+                       % (args.warmup, prewarm_evals, args.prewarm_s))
                       if use_graph else "one library call per iteration, eager launches",
             "plan": info,
         },

@@ -684,16 +684,30 @@ template <typename T> struct Engine final : schpf_ctx {
             td.minor_of.release(); td.n_virtual = 0;
             if (balance_now && sh.ring <= 1 && sh.waves_per_block >= 12) {   // the balanced kernels are 1024-thread ones
                 const double tb = now_s();
-                vminor.alloc((size_t)nnz * 4);
                 schpf::BalanceGeometry geo;
                 void *mo = nullptr;
-                schpf::balance_windows_device((void *)st, nnz, d_major, d_minor, side == 0 ? N : G, n_minor_plan, sh,
-                                              vminor.as<int32_t>(), &mo, geo);
-                td.minor_of.p = mo; td.minor_of.bytes = (size_t)geo.n_blocks * geo.n_virtual * 4;
-                td.n_virtual = geo.n_virtual;
-                d_minor = vminor.as<int32_t>();
-                n_minor_plan = geo.n_virtual;
-                presorted = false;
+                // the balancing needs ~20 bytes per nonzero of scratch and 4 bytes per (block, minor row) for good: a matrix
+                // that leaves no room for that is planned by index instead (the shape is valid for either)
+                bool balanced = true;
+                try {
+                    vminor.alloc((size_t)nnz * 4);
+                    schpf::balance_windows_device((void *)st, nnz, d_major, d_minor, side == 0 ? N : G, n_minor_plan, sh,
+                                                  vminor.as<int32_t>(), &mo, geo);
+                } catch (const std::invalid_argument &) {
+                    throw;
+                } catch (const std::exception &e) {
+                    (void)hipGetLastError();
+                    balanced = false;
+                    if (env_int("SCHPF_VERBOSE", 0))
+                        fprintf(stderr, "[schpf_hip]   balanced windows, side %d: not built (%s); windows by index\n", side, e.what());
+                }
+                if (balanced) {
+                    td.minor_of.p = mo; td.minor_of.bytes = (size_t)geo.n_blocks * geo.n_virtual * 4;
+                    td.n_virtual = geo.n_virtual;
+                    d_minor = vminor.as<int32_t>();
+                    n_minor_plan = geo.n_virtual;
+                    presorted = false;
+                } else vminor.release();
                 if (env_int("SCHPF_VERBOSE", 0))
                     fprintf(stderr, "[schpf_hip]   balanced windows, side %d: %d sections of %d windows, %.3f s\n", side,
                             geo.n_sections, geo.D, now_s() - tb);
