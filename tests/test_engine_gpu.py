@@ -473,6 +473,34 @@ def test_real_valued_data_and_stored_zeros_match_oracle(amd, oracle, dtype, plan
         assert_allclose(loss, want, rtol=1e-5 if f32 else 5e-7)
 
 
+@only_plans("tile", "balanced")
+@pytest.mark.parametrize("device_plan", ["1", "0"])
+def test_duplicate_entries_match_oracle(amd, oracle, plan_kind, device_plan, monkeypatch):
+    """A COO may hold an entry twice; the reference treats every stored entry as a nonzero of its own
+    (hpf_numba.py:97-112 runs over X.data) and so does the engine -- with both plan builders, and with the
+    balancing pass, whose keys (block, minor, lane group) then repeat."""
+    from scipy.sparse import coo_matrix
+    monkeypatch.setenv("SCHPF_DEVICE_PLAN", device_plan)
+    X0 = synthetic_counts(700, 900, 0.05, seed=31)
+    rng = np.random.RandomState(2)
+    pick = rng.choice(X0.nnz, 3000, replace=False)
+    row = np.concatenate([X0.row, X0.row[pick], X0.row[pick[:500]]])
+    col = np.concatenate([X0.col, X0.col[pick], X0.col[pick[:500]]])
+    data = np.concatenate([X0.data, X0.data[pick] + 1, np.ones(500, X0.data.dtype)])
+    perm = rng.permutation(len(data))
+    X = coo_matrix((data[perm], (row[perm], col[perm])), shape=X0.shape)    # NOT summed: nnz counts the repeats
+    assert X.nnz == X0.nnz + 3500
+    K, a, c = 12, 0.3, 0.3
+    bp, dp, st = random_state(oracle, X, K, np.float64, seed=3)
+    with load_engine(amd, X, K, np.float64, st, a, c, bp, dp) as eng:
+        for it in range(2):
+            eng.step()
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+            compare_state(eng, st, rtol=1e-11)
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate, st.beta_shape, st.beta_rate)
+        assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-11)
+
+
 def _subproblem_check(oracle, X, st_before, got, a, c, bp, dp, cells, genes, rtol, simultaneous=False):
     """Oracle comparison that scales to the benchmark sizes.  theta.shape[i] depends only on row
     i's nonzeros and the old tables, beta.shape[g] only on column g's; the rate updates need the
