@@ -292,7 +292,7 @@ void tile_plan_report(const TilePlanHost &P);
 // staged by LDS-DMA with one address per lane, so a window may be any `win_rows` rows of the table.
 // For every block the minor rows are therefore dealt to the windows greedily -- in minor order, each to
 // the window where the fullest of the block's rows that hold it stays lowest (ties: smallest sum of
-// those rows' loads, then the lowest window) -- inside SECTIONS of at most 64 consecutive windows (the
+// those rows' loads, then the lowest window) -- inside SECTIONS of at most 32 consecutive windows (the
 // staging of a window then reads a bounded stretch of the table, and the sections are independent work
 // for the builders).  Minor rows no row of the block holds fill the capacity left, in order.  A
 // simulation of the rule gives 0.77-0.82 at the C5 share and 0.90-0.92 at C3 with WHOLE windows (the
@@ -307,11 +307,12 @@ struct BalanceGeometry {
     int64_t n_blocks = 0;
     int n_virtual = 0;
 };
-// windows per section: at most 64 (the device builder's lanes), and the builders' load matrix [gpb][D] of 16-bit counts
-// within 60 KB
+// windows per section: at most 32 (64 = the device builder's lanes was measured: slot fill 0.81 -> 0.82, the same sweep
+// time, and a third longer to build -- the greedy is sequential inside a section), and the builders' load matrix
+// [gpb][D] of 16-bit counts within 60 KB
 inline void balance_sections(int n_windows, int gpb, int &n_sections, int &D)
 {
-    const int dmax = std::max(1, std::min(64, 30000 / std::max(gpb, 1)));
+    const int dmax = std::max(1, std::min(32, 30000 / std::max(gpb, 1)));
     n_sections = std::max(1, (n_windows + dmax - 1) / dmax);
     D = (n_windows + n_sections - 1) / n_sections;
     n_sections = (n_windows + D - 1) / D;
