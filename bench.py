@@ -8,13 +8,16 @@ schpf/scHPF_.py:657-714) over the whole synthetic count matrix.  The default wor
 BASELINE.json's headline configuration C3: 100k cells x 20k genes, ~5 % nonzeros, K = 20,
 float64 (the reference's default dtype), inputs resident in HBM before timing starts.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME global shape is
-row-sharded over the ranks (strong scaling, BASELINE.json configs[3]): rank r draws its own
-block of N/P cells, and every iteration does one RCCL all-reduce of the G*K + K gene-side
-sums.
+For N > 1 (one rank per GPU: launched by torch.distributed.run, or -- when `--gpus N` is given
+without a launcher -- by this script re-executing itself under it) the SAME matrix (seed 42) is
+row-sharded over the ranks by the product's own nnz-balanced partition
+(schpf_amd.sharded.row_partition; strong scaling, BASELINE.json configs[3]): rank r keeps rows
+[bounds[r], bounds[r+1]), and every iteration does one RCCL all-reduce of the G*K + K
+gene-side sums.
 
 Prints ONE JSON line on rank 0, carrying the driver's contract fields plus
-  roofline     : dominant kernel (the sweep) against the HBM roof, HIP-event timed
+  roofline     : dominant kernel (the sweep), HIP-event timed, against BOTH roofs -- algorithmic bytes vs
+                 HBM and the essential FMAs vs the vector-FP peak of the dtype; `bound` names the nearer one
   cpu_baseline : the CPU oracle in the reference's execution shape on this box's cores
 """
 import argparse
@@ -41,19 +44,45 @@ CONFIGS = {
     "c4-shard4": (25_000, 20_000, 0.05, 20),     # ... of --gpus 4
 }
 HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+# vector (VALU) FMA peaks: FP32 157.3 TFLOP/s (MI355X_MICROARCH.md, chip-level table); FP64 vector is half of it,
+# 78.6 TFLOP/s (public MI355X spec; 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz) -- the sweep has no MFMA work
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
 
 
 def synthetic_block(ncells, ngenes, density, seed):
     """Generator A of SURVEY.md 8(d) = the reference's test-fixture recipe
-    (tests/conftest.py:14-25): negative-binomial counts at uniform positions, dups summed."""
+    (tests/conftest.py:14-25): negative-binomial counts at uniform positions, dups summed.
+    Same draws in the same order as the fixture; the duplicates are summed by sorting packed
+    (row, col, count) keys and adding up runs -- entry for entry what coo_matrix.sum_duplicates
+    returns (canonical row-major order), in less than half the time at 1e8 draws (its lexsort)."""
     rng = np.random.RandomState(seed)
     nnz = int(round(ncells * ngenes * density))
-    x = rng.negative_binomial(2, 0.5, nnz).astype(np.int32)
+    x = rng.negative_binomial(2, 0.5, nnz)
     x[x == 0] = 1
-    row = rng.randint(0, ncells, nnz).astype(np.int32)
-    col = rng.randint(0, ngenes, nnz).astype(np.int32)
-    X = coo_matrix((x, (row, col)), shape=(ncells, ngenes), dtype=np.int32)
-    X.sum_duplicates()
+    if nnz == 0 or int(x.max()) > 255 or ncells * ngenes >= 2 ** 54:   # the count must fit 8 key bits
+        row = rng.randint(0, ncells, nnz).astype(np.int32)
+        col = rng.randint(0, ngenes, nnz).astype(np.int32)
+        X = coo_matrix((x.astype(np.int32), (row, col)), shape=(ncells, ngenes), dtype=np.int32)
+        X.sum_duplicates()
+        return X
+    bits = max(1, int(ngenes - 1).bit_length())
+    key = rng.randint(0, ncells, nnz).astype(np.int64)
+    key <<= bits
+    key |= rng.randint(0, ngenes, nnz)
+    key <<= 8
+    key |= x
+    del x
+    key.sort()
+    pos = key >> 8
+    first = np.empty(nnz, dtype=bool)
+    first[:1] = True
+    np.not_equal(pos[1:], pos[:-1], out=first[1:])
+    idx = np.flatnonzero(first)
+    counts = np.add.reduceat(key & 255, idx).astype(np.int32)
+    pos = pos[idx]
+    X = coo_matrix((counts, ((pos >> bits).astype(np.int32), (pos & ((1 << bits) - 1)).astype(np.int32))),
+                   shape=(ncells, ngenes), dtype=np.int32)
+    X.has_canonical_format = True
     return X
 
 
@@ -191,18 +220,24 @@ def algorithmic_bytes(nnz, N, G, K, itemsize):
     return 12 * nnz + 4 * K * itemsize * (N + G) + 2 * itemsize * (N + G)
 
 
-def init_engine(eng, X, K, dtype, seed=0):
-    """Random init exactly as scHPF._setup (reference scHPF_.py:783-844), hypers empirical."""
+def init_engine(eng, X, K, dtype, seed=0, whole=None, rows=None):
+    """Random init exactly as scHPF._setup (reference scHPF_.py:783-844), hypers empirical.  A rank of a
+    sharded run passes the WHOLE matrix as `whole` and its row range as `rows`: hyperparameters and the
+    random start are those of the unsharded fit (what scHPF.fit(X, devices=[...]) does), the rank uploads
+    its block `X` and its slices of xi / theta."""
     from schpf import scHPF
     np.random.seed(seed)
     m = scHPF(K, dtype=dtype)
-    bp, dp, xi, eta, theta, beta = m._setup(X, freeze_genes=False, reinit=True)
+    bp, dp, xi, eta, theta, beta = m._setup(X if whole is None else whole, freeze_genes=False, reinit=True)
     xi.vi_shape[:] = m.ap + K * m.a
     eta.vi_shape[:] = m.cp + K * m.c
     eng.upload(X)
     eng.set_hypers(m.a, m.c, bp, dp)
-    for name, g in (("xi", xi), ("theta", theta), ("eta", eta), ("beta", beta)):
-        eng.set_gamma(name, g.vi_shape, g.vi_rate)
+    sl = slice(None) if rows is None else slice(int(rows[0]), int(rows[1]))
+    eng.set_gamma("xi", xi.vi_shape[sl], xi.vi_rate[sl])
+    eng.set_gamma("theta", theta.vi_shape[sl], theta.vi_rate[sl])
+    eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
+    eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
     return bp, dp, (xi, eta, theta, beta)
 
 
@@ -523,6 +558,17 @@ def main():
     # the host driver of these boxes only supports dmabuf IPC: without this RCCL fails at the first
     # cross-process buffer exchange (hipIpcGetMemHandle: invalid argument)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  One rank per GPU under
+        # torch.distributed.run on this node (127.0.0.1, a free port); rank 0 prints the one JSON line.
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                  str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     import torch
     import torch.distributed as dist
 
@@ -530,9 +576,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
-                             "--gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if args.same_gpu:
         local_rank = 0
     if args.backend == "gloo" and args.comm != "torch":
@@ -549,24 +593,35 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
 
     from schpf_amd import DeviceCAVI
-    from schpf_amd.sharded import ShardedCAVI, exchange_tensor_of
+    from schpf_amd.sharded import ShardedCAVI, exchange_tensor_of, row_partition, take_rows
 
     N, G, density, K = CONFIGS[args.config]
     dtype = np.float64 if args.dtype == "f64" else np.float32
     itemsize = np.dtype(dtype).itemsize
-    n_local = N // world + (1 if rank < N % world else 0)
-    if n_local * G * density > 2e8:     # all of C5 on few GPUs: the threaded slab generator (seconds, not minutes)
-        X = synthetic_slabs(n_local, G, density, seed=42 + 1000 * rank)
+    # ONE matrix for every N: generator A with seed 42 (what BENCH's N = 1 line times).  With N > 1 every rank draws
+    # it (deterministic; nothing but the communicator id travels between the ranks) and keeps its block of the
+    # product's nnz-balanced row partition -- the split scHPF.fit(X, devices=[...]) makes.
+    if N * G * density > 2e8:           # all of C5: the threaded slab generator (seconds, not minutes)
+        X = synthetic_slabs(N, G, density, seed=42)
     else:
-        X = synthetic_block(n_local, G, density, seed=42 + 1000 * rank)
+        X = synthetic_block(N, G, density, seed=42)
+    nnz_total = int(X.nnz)
+    bounds = row_partition(X, world)
+    whole, my_rows = None, None
+    if world > 1:
+        my_rows = (int(bounds[rank]), int(bounds[rank + 1]))
+        whole = X
+        X, _ = take_rows(whole, *my_rows)
+    n_local = X.shape[0]
 
     # the engine enqueues on a stream of its own; ShardedCAVI orders the collective with it
     eng = DeviceCAVI(n_local, G, K, dtype=dtype, device=local_rank)
     if sharded:
         eng.hint_sharded()
     t_up = time.perf_counter()
-    init_engine(eng, X, K, dtype)
+    init_engine(eng, X, K, dtype, whole=whole, rows=my_rows)
     upload_s = time.perf_counter() - t_up
+    del whole
     nnz_local = X.nnz
     # one library call for all K timed iterations, as scHPF.fit issues them between two loss checks: a
     # hipGraph replay on one GPU (an odd K: K - 1 iterations replayed + one eager), and for sharded runs
@@ -580,20 +635,13 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         drv = NativeShard(eng, uid[0], rank, world)
         step = drv.step
-        nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
-        dist.all_reduce(nnz_t)
-        nnz_total = int(nnz_t.item())
         loss_fn = drv.mean_negative_pois_llh
     elif sharded:
         drv = ShardedCAVI(eng, exchange_tensor_of(eng, local_rank))
         step = drv.step
-        nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device="cuda")
-        dist.all_reduce(nnz_t)
-        nnz_total = int(nnz_t.item())
         loss_fn = drv.mean_negative_pois_llh
     else:
         step = eng.step
-        nnz_total = nnz_local
         loss_fn = eng.mean_negative_pois_llh
 
     def fence():
@@ -670,6 +718,25 @@ def main():
     b_launch = b_iter / per_iter
     achieved = b_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
     info = eng.plan_info()
+    # The compute roof of the same launch.  Essential arithmetic of the two-pass form: per stored nonzero and
+    # orientation K FMAs for the normaliser s = sum_k Et[i,k] Eb[g,k] and K FMAs for acc_k += (x / s) Eb[g,k]
+    # (sweep_impl.h pipe_step) = 4 K FMAs = 8 K flop per nonzero over both orientations (the reciprocal, the
+    # cross-lane sum, decode and addressing are overhead, not counted).  Vector FP peak of the dtype, no MFMA.
+    flops_iter = 8.0 * K * nnz_local
+    flops_launch = flops_iter / per_iter
+    valu_peak = VALU_PEAK_TFLOPS[args.dtype]
+    valu_achieved = flops_launch / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
+    hbm_frac, valu_frac = achieved / HBM_PEAK_GBS, valu_achieved / valu_peak
+    # what the kernel issues for it (tile plans): FMA wave-instructions = 2 sides x nnz x 2 KL / (64 / LPC) lane
+    # groups per wave; the step slots the plan stores (two nonzeros each) say how many of the executed steps
+    # carry nonzeros; per wave step the f64 paired loop issues ~2 x 2 KL FMAs + 24 other VALU instructions
+    # (rocprofv3 SQ_INSTS_VALU in profiles/)
+    slots = info["entry_slots_cell"] + info["entry_slots_gene"]
+    tile = info["chunk_len"] < 0
+    slot_fill = (nnz_local / float(slots)) if (tile and slots) else None
+    kl, lpc = info["KL"], info["LPC"]
+    fma_wave_insts = 4.0 * kl * nnz_local / (64.0 / lpc)
+    essential_over_issued = (4.0 * kl) / (4.0 * kl + 24.0) if (tile and args.dtype == "f64") else None
     # the counters were collected on the one-launch (dual) iteration of a single GPU
     traffic, traffic_src = static_traffic(args.config, args.dtype, info) if not sharded else (None, None)
 
@@ -681,11 +748,13 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": "%s: synthetic %d cells x %d genes, density %.3f (negative-binomial counts, "
-                        "RandomState(42+1000*rank) per row block), nnz %d after summing duplicates, "
+                        "RandomState(42), the same matrix for every N), nnz %d after summing duplicates, "
                         "K=%d, one CAVI iteration per step (no loss evaluation inside the step)"
                         % (args.config.upper(), N, G, density, nnz_total, K),
-            "parallelism": ("cells row-sharded x%d, one RCCL all-reduce of G*K+K per iteration (%s)"
-                            % (world, "issued by the library" if args.comm == "library" else "torch.distributed"))
+            "parallelism": ("cells row-sharded x%d by schpf_amd.sharded.row_partition (nnz-balanced contiguous row "
+                            "blocks; this rank: rows %d..%d, nnz %d), one RCCL all-reduce of G*K+K per iteration (%s)"
+                            % (world, my_rows[0], my_rows[1], nnz_local,
+                               "issued by the library" if args.comm == "library" else "torch.distributed"))
                            if world > 1 else "single GPU",
             "launch": ("one library call for the %d timed iterations (%s), after %d untimed iterations of the same call"
                        % (args.steps, "schpf_steps_sharded; a hipGraph with one rank or SCHPF_GRAPH_SHARDED=1" if sharded
@@ -696,13 +765,30 @@ def main():
             "plan": info,
         },
         "roofline": {
-            "bound": "hbm",
+            # the nearer roof of the two below; `achieved` / `peak` / `frac` keep SURVEY 8(d)'s definition
+            # (algorithmic bytes per launch / launch time against the HBM peak) whichever one binds
+            "bound": "valu_fp%d" % (8 * itemsize) if valu_frac > hbm_frac else "hbm",
             "kernel": ("tile_sweep_dual_kernel (cell-side + gene-side sweep in one launch; algorithmic "
                        "bytes per launch = B_iter" if per_iter == 1 else
                        "tile_sweep_kernel (cell + gene launches; algorithmic bytes per launch = B_iter/2")
                       + ", B_iter = 12*nnz + 4*K*s*(N+G) + 2*s*(N+G))",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_frac": hbm_frac,
+            "valu": {
+                "what": "essential FMAs of the launch against the vector FP%d peak (no MFMA on this path): 4 K FMAs = "
+                        "8 K flop per nonzero over both orientations (K for the normaliser + K for the accumulation, "
+                        "per side)" % (8 * itemsize),
+                "flops_per_launch": flops_launch, "achieved": valu_achieved, "peak": valu_peak, "unit": "TFLOP/s",
+                "frac": valu_frac,
+                "fma_wave_instructions_per_launch": fma_wave_insts / per_iter,
+                "essential_over_issued_valu": essential_over_issued,
+                "slot_fill": slot_fill,
+                "note": "essential_over_issued_valu = FMAs / (FMAs + the ~24 other VALU instructions of a wave step of "
+                        "the f64 paired loop); slot_fill = share of the stored step slots that carry a nonzero (a padding "
+                        "slot executes every instruction of a nonzero); measured SQ_INSTS_VALU per launch: profiles/",
+            },
+            "fp%d_valu_frac" % (8 * itemsize): valu_frac,
             "algorithmic_gb_per_launch": b_launch / 1e9, "sweep_launches_per_iteration": per_iter,
             "avg_launch_ms": sweep_ms, "launches": sweeps,
             "timed_with": ("HIP events on the engine's stream around every launch, over a second pass of the same %d "

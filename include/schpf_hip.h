@@ -29,6 +29,10 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden and an export list (csrc/libschpf_hip.map): the functions declared
+ * between this pragma and its pop are everything the shared object exports */
+#pragma GCC visibility push(default)
+
 #define SCHPF_F32 0
 #define SCHPF_F64 1
 
@@ -258,6 +262,8 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
  * sums; development builds with -DSCHPF_ABLATE=9 leave each persistent workgroup's finishing time there,
  * tools/tail_study.py). */
 int schpf_debug_read_wave_out(schpf_ctx *ctx, double *out, int64_t n);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,13 @@ class SchpfHipError(RuntimeError):
     pass
 
 
+def is_out_of_memory(exc):
+    """True if a library error is HIP's out-of-memory (hipMalloc / graph instantiation) -- the only failure the
+    callers' "does not fit, try a smaller layout" fallbacks are meant for."""
+    msg = str(exc).lower()
+    return "out of memory" in msg or "hiperroroutofmemory" in msg or "memory allocation" in msg
+
+
 def build(force=False):
     """Compile libschpf_hip.so for gfx950 with hipcc (schpf_amd/csrc/Makefile)."""
     csrc = os.path.join(_HERE, "csrc")

@@ -800,10 +800,14 @@ template <typename T> struct Engine final : schpf_ctx {
     // floor); a 1/8 shard of C3 keeps the large workgroup in f64 (525 pairs) and halves it in f32 (-3 %).
     int cu_count = 256;
     int n_cu() const { return cu_count; }
+    // workgroups of a tile sweep that fit a compute unit at once.  Sized by the LOSS pass's LDS (window + the 1 KiB
+    // logarithm table behind it, run_sweep): the PHI and LLH launches of a plan must agree on the residency
+    static int per_cu(size_t window_lds_bytes) { return window_lds_bytes + 1024 > 80 * 1024 ? 1 : 2; }
     void pick_workgroup(int n_major, int n_minor, int &wpb, int &lds_kb) const
     {
         wpb = env_int("SCHPF_WPB", 0);
-        lds_kb = env_int("SCHPF_LDS_KB", 0);
+        // <= 158 KiB: the loss pass adds a 1 KiB table behind the window and the kernels opt in to 159 KiB
+        lds_kb = std::min(env_int("SCHPF_LDS_KB", 0), 158);
         const size_t row_bytes = (size_t)KP * sizeof(T);
         if (!wpb) {
             wpb = 16;
@@ -919,7 +923,12 @@ template <typename T> struct Engine final : schpf_ctx {
         {
             const int half_env = env_int("SCHPF_HALF", -1);
             int n_slots = half_env >= 2 ? half_env : 0;
-            if (balance_now && half_env < 2) n_slots = 0;      // balanced windows are whole windows (plan.h)
+            // balanced windows are whole windows (plan.h).  Decided for the upload, not per side: the library only
+            // balances matrices with < 24 nonzeros per row and whole window, i.e. < 12 per half window, where the rule
+            // below (>= 16) would not pick half windows either -- a side that then is NOT balanced (too small a
+            // workgroup, no memory for the scratch) gets the same whole index-cut windows it would have got without
+            // balancing.  Only a forced SCHPF_BALANCE=1 on a dense matrix can lose the half-window schedule this way.
+            if (balance_now && half_env < 2) n_slots = 0;
             else if (force_half >= 0) n_slots = force_half ? 2 : 0;
             else if (half_env < 0 && sh.ring <= 1 && wpb >= 12) {
                 const int64_t half_rows = ((int64_t)lds_kb * 512 - 64) / (int64_t)row_bytes;
@@ -1018,8 +1027,7 @@ template <typename T> struct Engine final : schpf_ctx {
                 // faster for it (C5 2.48 vs 2.42 ms, C3 f32 +10 %: coarser tail): the window copy is bound by
                 // the CU's own LDS-DMA rate, not by where the rows come from (tools/micro/stage_bench.hip)
                 const schpf::TilePlanHost *both[2] = {&hc, &hg};
-                const int per_cu = tcell.lds_bytes > 80 * 1024 ? 1 : 2;
-                schpf::xcd_launch_order(both, 2, n_xcd, n_cu() / n_xcd * per_cu, ord);
+                schpf::xcd_launch_order(both, 2, n_xcd, n_cu() / n_xcd * per_cu(tcell.lds_bytes), ord);
             } else {
                 ord.reserve((size_t)(hc.n_tasks + hg.n_tasks));
                 size_t i = 0, j = 0;   // merge of two lists already sorted by decreasing work
@@ -1314,7 +1322,7 @@ template <typename T> struct Engine final : schpf_ctx {
             a.seed = seed; a.major_is_cell = cellside ? 1 : 0;
             if (mode != schpf::MODE_RANDOM && env_int("SCHPF_PERSISTENT", 1)) {   // see step_local
                 a.queue = dual_queue.as<int>();
-                a.resident = n_cu() * (td.lds_bytes > 80 * 1024 ? 1 : 2);
+                a.resident = n_cu() * per_cu(td.lds_bytes);
                 a.task_order = td.task_order.as<int>();
             }
             // the loss pass keeps a 1 KiB logarithm table behind the window (sweep_impl.h LlhAccumulator)
@@ -1422,7 +1430,7 @@ template <typename T> struct Engine final : schpf_ctx {
             int resident = 0;
             if (env_int("SCHPF_PERSISTENT", 1)) {
                 queue = dual_queue.as<int>();
-                resident = n_cu() * (lds > 80 * 1024 ? 1 : 2);
+                resident = n_cu() * per_cu(lds);
             }
             HIPCHK(schpf::launch_tile_sweep_dual<T>(ac, ag, dual_order.as<int>(), NV, LPC, tcell.packed ? 1 : 0,
                                                     dual_slots, tcell.threads, lds, queue, resident, stream));
@@ -1570,7 +1578,7 @@ template <typename T> struct Engine final : schpf_ctx {
         const int forced = env_int("SCHPF_LOSS_SIDE", -1);
         if (forced == 0 || forced == 1) return use_tile ? forced : 0;
         if (!use_tile || wave_out.bytes < (size_t)tgene.n_wave_out * sizeof(double)) return 0;
-        const int64_t resident = (int64_t)n_cu() * (tcell.lds_bytes > 80 * 1024 ? 1 : 2);
+        const int64_t resident = (int64_t)n_cu() * per_cu(tcell.lds_bytes);
         return (tcell.n_tasks < 2 * resident && tgene.n_tasks > tcell.n_tasks) ? 1 : 0;
     }
 
@@ -1874,9 +1882,11 @@ int schpf_comm_unique_id(void *out128)
 int schpf_comm_init(schpf_ctx *ctx, const void *unique_id128, int rank, int world)
 {
     if (!unique_id128) return fail("unique_id is NULL");
-    CTX_CALL(ctx->comm_init(unique_id128, rank, world));
+    // a cached hipGraph of a sharded stretch holds an all-reduce bound to the communicator it was captured with: every
+    // cached graph goes before the communicator does (hypers_changed() is "drop the captured graphs")
+    CTX_CALL(ctx->hypers_changed(); ctx->comm_init(unique_id128, rank, world));
 }
-int schpf_comm_destroy(schpf_ctx *ctx) { CTX_CALL(ctx->comm_destroy()); }
+int schpf_comm_destroy(schpf_ctx *ctx) { CTX_CALL(ctx->hypers_changed(); ctx->comm_destroy()); }
 int schpf_hint_sharded(schpf_ctx *ctx, int on) { CTX_CALL(ctx->hint_sharded(on)); }
 int schpf_hint_transient(schpf_ctx *ctx, int on) { CTX_CALL(ctx->hint_transient(on)); }
 int schpf_keep_rows(schpf_ctx *ctx, int on) { CTX_CALL(ctx->keep_rows(on)); }

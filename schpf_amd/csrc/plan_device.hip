@@ -4,8 +4,10 @@
 // offsets) is the shared host code of plan.cpp.  The result is bit-identical to the host
 // builder's (tests/test_engine_gpu.py::test_device_plan_equals_host_plan) -- it only takes a
 // tenth of the time, which matters because a whole fit at 1e8 nonzeros is ~0.3 s of iterations.
+#include <cstring>
+
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <chrono>
 #include <cstdint>
@@ -443,10 +445,10 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(nnz, threads)), dim3(threads), 0, st, nnz, d_major, d_minor,
                            minor_bits, k_in.as<uint64_t>(), i_in.as<int32_t>());
         size_t temp_bytes = 0;
-        PD_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(),
+        PD_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(),
                                                     i_in.as<int32_t>(), order, (int)nnz, 0, end_bit, st));
         Tmp temp(temp_bytes);
-        PD_CHECK(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(),
+        PD_CHECK(rocprim::radix_sort_pairs(temp.p, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(),
                                                     i_in.as<int32_t>(), order, (int)nnz, 0, end_bit, st));
         hipLaunchKernelGGL(split_keys_kernel, dim3(grid_for(nnz, threads)), dim3(threads), 0, st, nnz,
                            k_out.as<uint64_t>(), order, d_val, minor_bits, sm.as<int32_t>(), sn.as<int32_t>(),
@@ -786,10 +788,10 @@ void balance_windows_device(void *stream, int64_t nnz, const int32_t *d_major, c
             hipLaunchKernelGGL(balance_keys_kernel, dim3(grid_for(nnz, threads)), dim3(threads), 0, st, nnz, d_major, d_minor,
                                d_slot.as<int32_t>(), gpb, minor_bits, k_in.as<uint64_t>());
             size_t temp_bytes = 0;
-            PD_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (int)nnz,
+            PD_CHECK(rocprim::radix_sort_keys(nullptr, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (int)nnz,
                                                        0, end_bit, st));
             Tmp temp(temp_bytes);
-            PD_CHECK(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (int)nnz,
+            PD_CHECK(rocprim::radix_sort_keys(temp.p, temp_bytes, k_in.as<uint64_t>(), k_out.as<uint64_t>(), (int)nnz,
                                                        0, end_bit, st));
             PD_CHECK(hipStreamSynchronize(st));   // temp dies here
         }

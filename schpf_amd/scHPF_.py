@@ -495,14 +495,24 @@ class scHPF(BaseEstimator):
             Xsum = Xcsr.tocoo() if duplicates else X
 
             def whole_matrix_engine(M, keep):
-                e = DeviceCAVI(M.shape[0], M.shape[1], nfactors, dtype=dtype, device=device)
+                # None = "does not fit": only HIP's out-of-memory takes the fallback chain below; invalid input
+                # or any other failure is the caller's to see
+                e = None
                 try:
+                    e = DeviceCAVI(M.shape[0], M.shape[1], nfactors, dtype=dtype, device=device)
                     if keep:
                         e.keep_rows()
                     e.upload(M)
-                except _lib.SchpfHipError:
-                    e.close()
+                except _lib.SchpfHipError as exc:
+                    if e is not None:
+                        e.close()
+                    if not _lib.is_out_of_memory(exc):
+                        raise
                     return None
+                except BaseException:
+                    if e is not None:
+                        e.close()
+                    raise
                 return stack.enter_context(e)
 
             source = whole_matrix_engine(Xsum, True)

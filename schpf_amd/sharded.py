@@ -18,6 +18,8 @@ With freeze_genes (project) there is nothing to exchange.  The loss needs a seco
 (step_local / step_finish / exchange_tensor / loss_terms) so the protocol is testable
 on CPU with the gloo backend and an oracle-backed engine (tests/test_sharded_cpu.py).
 """
+import inspect
+
 import numpy as np
 
 __all__ = ["row_partition", "take_rows", "ShardedCAVI", "exchange_tensor_of", "ThreadedShards", "NativeShard"]
@@ -157,9 +159,9 @@ class ThreadedShards(object):
             eng = make_engine(hi - lo, self.ngenes, self.nfactors, dtype=self.dtype, device=self.devices[rank])
             try:
                 eng.hint_sharded()
-                try:
+                if "warn" in inspect.signature(eng.upload).parameters:
                     eng.upload(sub, warn=False)    # a pool thread must not touch the warnings machinery
-                except TypeError:                  # stand-in engines of the CPU tests take no `warn`
+                else:                              # stand-in engines of the CPU tests take no `warn`
                     eng.upload(sub)
             except BaseException:
                 eng.close()
@@ -188,8 +190,15 @@ class ThreadedShards(object):
         except BaseException:
             self.close()
             raise
-        if self.engines and hasattr(self.engines[0], "rounding_warning"):
-            self.engines[0].rounding_warning(stacklevel=3)   # once, on the calling thread
+        if self.engines and hasattr(self.engines[0], "upload_info"):
+            # values rounded to float32 in ANY shard, reported once and on the calling thread
+            infos = [e.upload_info() for e in self.engines]
+            rounded = sum(i["rounded"] for i in infos)
+            if rounded:
+                import warnings
+                warnings.warn("%d of %d values of X.data are not exactly representable in float32 and were "
+                              "rounded (relative error <= 6e-8); counts are stored as float32 on the device"
+                              % (rounded, sum(i["nnz"] for i in infos)), RuntimeWarning, stacklevel=3)
         if comm != "rccl":
             self._views = [e.exchange if hasattr(e, "exchange") else exchange_tensor_of(e, d)
                            for e, d in zip(self.engines, self.devices)]

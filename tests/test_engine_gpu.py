@@ -551,12 +551,13 @@ def _subproblem_check(oracle, X, st_before, got, a, c, bp, dp, cells, genes, rto
 import functools
 
 
-@functools.lru_cache(maxsize=1)
+@functools.lru_cache(maxsize=2)
 def _bench_matrix(N, G, dens):
     if N * G * dens > 2e8:      # all of C5: bench.py's threaded slab generator (5e8 draws in well under a minute)
         from bench import synthetic_slabs
         return synthetic_slabs(N, G, dens, seed=42)
-    return synthetic_counts(N, G, dens, seed=42)    # bench.py's generator A, same seed
+    from bench import synthetic_block               # bench.py's generator A, same seed: entry for entry
+    return synthetic_block(N, G, dens, seed=42)     # synthetic_counts(...) (tests/test_bench_host.py), faster
 
 
 BENCH_SHAPES = [   # the workloads bench.py times (BASELINE.json configs[2] and the per-GPU share of configs[4])
@@ -567,6 +568,115 @@ BENCH_SHAPES = [   # the workloads bench.py times (BASELINE.json configs[2] and 
     # ALL of C5 (BASELINE.json configs[4]: 1M x 25k, 2 %, K=50, nnz 4.95e8) on one GPU, in the default run
     pytest.param(1000000, 25000, 0.02, 50, np.float64, id="C5whole-f64"),
 ]
+
+
+_C3_UNSHARDED = {}
+
+
+def _c3_unsharded_run(amd, oracle, dtype):
+    """Two iterations + the loss of ONE engine on the C3 matrix from the seed-0 start: the states after each
+    iteration and the loss, computed once per dtype and kept for the shard counts of the test below."""
+    key = np.dtype(dtype).name
+    if key not in _C3_UNSHARDED:
+        X = _bench_matrix(100000, 20000, 0.05)
+        bp, dp, st = random_state(oracle, X, 20, dtype, seed=0)
+        states = []
+        with load_engine(amd, X, 20, dtype, st, 0.3, 0.3, bp, dp) as eng:
+            for _ in range(2):
+                eng.step()
+                states.append({n: eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")})
+            loss = eng.mean_negative_pois_llh()
+        _C3_UNSHARDED[key] = (states, loss)
+    return _C3_UNSHARDED[key]
+
+
+@only_plans("tile")
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("nshards", [2, 4, 8])
+def test_c4_row_shards_of_c3_match_oracle_and_the_unsharded_engine(amd, oracle, plan_kind, nshards, dtype):
+    """BASELINE.json configs[3] AT ITS SIZE on the one GPU a test box has: the C3 matrix (100k x 20k, 5 %, K = 20,
+    nnz 9.75e7) split by the product's nnz-balanced row_partition into 2 / 4 / 8 shard engines on device 0
+    (ThreadedShards: hint_sharded plans, the two-launch sharded iteration, the packing and update-from-exchange
+    kernels; comm="emulated": the all-reduce is the sum of the shards' exchange buffers, because RCCL refuses
+    several ranks on one device).  Two iterations, each checked (i) against the oracle's own iteration on ~500
+    sampled cells and ~500 sampled genes and (ii) against the unsharded DeviceCAVI on ALL rows -- the sharded
+    sum order differs, hence round-off tolerances: rtol 1e-11 (f64) / 2e-5 (f32); then the loss over all
+    nonzeros against the unsharded engine and the oracle."""
+    from schpf_amd.sharded import ThreadedShards
+    N, G, K, a, c = 100000, 20000, 20, 0.3, 0.3
+    X = _bench_matrix(N, G, 0.05)
+    f32 = np.dtype(dtype) == np.float32
+    tol = 2e-5 if f32 else 1e-11
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=0)
+    ref_states, ref_loss = _c3_unsharded_run(amd, oracle, dtype)
+    rng = np.random.RandomState(11 + nshards)
+    cells = np.sort(rng.choice(N, 500, replace=False))
+    genes = np.sort(rng.choice(G, 500, replace=False))
+    with ThreadedShards(X, K, dtype, devices=[0] * nshards, comm="emulated") as shards:
+        assert shards.world == nshards and int(shards.bounds[-1]) == N
+        per_shard = np.diff(np.concatenate([[0], np.cumsum(np.bincount(X.row, minlength=N))])[shards.bounds])
+        assert per_shard.max() - per_shard.min() <= 2 * np.bincount(X.row, minlength=N).max()   # nnz-balanced
+        shards.set_hypers(a, c, bp, dp)
+        for name in ("xi", "theta", "eta", "beta"):
+            shards.set_gamma(name, getattr(st, name + "_shape"), getattr(st, name + "_rate"))
+        for it in range(2):
+            shards.steps(1)
+            got = {n: shards.get_gamma(n) for n in ("xi", "theta", "eta", "beta")}
+            _subproblem_check(oracle, X, st, got, a, c, bp, dp, cells, genes, rtol=tol)
+            for name in ("xi", "theta", "eta", "beta"):
+                assert_allclose(got[name][0], ref_states[it][name][0], rtol=tol, err_msg="%s shape vs unsharded" % name)
+                assert_allclose(got[name][1], ref_states[it][name][1], rtol=tol, err_msg="%s rate vs unsharded" % name)
+            for e in shards.engines[1:]:     # the replicas of beta / eta agree bitwise with shard 0's
+                for name in ("eta", "beta"):
+                    s_r = e.get_gamma(name)
+                    assert np.array_equal(s_r[0], got[name][0]) and np.array_equal(s_r[1], got[name][1])
+            st = oracle.State(got["xi"][0], got["xi"][1], got["theta"][0], got["theta"][1],
+                              got["eta"][0], got["eta"][1], got["beta"][0], got["beta"][1])
+        loss = shards.mean_negative_pois_llh()
+    assert_allclose(loss, ref_loss, rtol=1e-5 if f32 else 1e-11)
+    want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                         st.beta_shape, st.beta_rate, nthreads=16)
+    assert_allclose(loss, want, rtol=1e-5 if f32 else 1e-11)
+
+
+SHARD_SHAPES = [   # what a rank of bench.py --gpus 8 / 4 / 2 holds of C3 (bench.py CONFIGS c4-shard, -shard4, -shard2)
+    pytest.param(12500, id="1of8"), pytest.param(25000, id="1of4"), pytest.param(50000, id="1of2"),
+]
+
+
+@only_plans("tile")
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("ncells", SHARD_SHAPES)
+def test_shard_shapes_with_sharded_plans_match_oracle_on_sampled_rows(amd, oracle, plan_kind, ncells, dtype):
+    """The row-shard shapes of C3 with the plans a rank really gets (schpf_hint_sharded: task ranges for two sweep
+    launches, the half-window rule from 256 (block, window) pairs) through the library-driven sharded iteration
+    (one-rank RCCL communicator: gene sweep, packing, all-reduce, cell sweep, update from the exchange buffer):
+    sampled rows against the oracle, conservation over all rows, the loss over all nonzeros."""
+    from schpf_amd.sharded import NativeShard
+    G, K, a, c = 20000, 20, 0.3, 0.3
+    X = synthetic_counts(ncells, G, 0.05, seed=42)
+    f32 = np.dtype(dtype) == np.float32
+    tol = 2e-5 if f32 else 1e-11
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=0)
+    rng = np.random.RandomState(5)
+    cells = np.sort(rng.choice(ncells, 400, replace=False))
+    genes = np.sort(rng.choice(G, 400, replace=False))
+    rows = np.asarray(X.sum(1)).ravel(); cols = np.asarray(X.sum(0)).ravel()
+    with load_shard_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+        shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)
+        for it in range(2):
+            shard.steps(1)
+            got = {n: eng.get_gamma(n) for n in ("xi", "theta", "eta", "beta")}
+            _subproblem_check(oracle, X, st, got, a, c, bp, dp, cells, genes, rtol=tol)
+            ths, bes = got["theta"][0].astype(np.float64), got["beta"][0].astype(np.float64)
+            assert_allclose((ths - a).sum(1), rows, rtol=tol, atol=tol)
+            assert_allclose((bes - c).sum(1), cols, rtol=tol, atol=tol * 10)
+            st = oracle.State(got["xi"][0], got["xi"][1], got["theta"][0], got["theta"][1],
+                              got["eta"][0], got["eta"][1], got["beta"][0], got["beta"][1])
+        loss = shard.mean_negative_pois_llh()
+    want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                         st.beta_shape, st.beta_rate, nthreads=16)
+    assert_allclose(loss, want, rtol=1e-5 if f32 else 1e-11)
 
 
 @only_plans("tile")

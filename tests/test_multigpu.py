@@ -116,6 +116,42 @@ def test_bench_line_of_two_ranks_on_one_gpu():
     assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (no WORLD_SIZE in the environment): the script
+    re-executes itself under torch.distributed.run and rank 0 prints exactly one JSON line.  Both ranks on
+    device 0 over gloo, as above.  The matrix is the N = 1 matrix (seed 42) split by row_partition: the line's
+    nnz is the unsharded nnz."""
+    from bench import synthetic_block, CONFIGS
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "c2", "--steps", "10", "--warmup", "3",
+                        "--comm", "torch", "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--no-converge",
+                        "--no-traffic"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["scaling"] == "strong"
+    N, G, dens, K = CONFIGS["c2"]
+    nnz = synthetic_block(N, G, dens, seed=42).nnz
+    assert "nnz %d " % nnz in line["config"]["workload"]
+    assert "row_partition" in line["config"]["parallelism"]
+    assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_self_launch_over_real_devices(world):
+    """The driver's N > 1 line if it is NOT wrapped in a launcher: `python bench.py --gpus N` over RCCL."""
+    need_gpus(world)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--config", "c2", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline", "--no-converge", "--no-traffic"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world and np.isfinite(line["value"]) and line["value"] > 0
+
+
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_bench_line_over_ranks(world):
     """The driver's launch line for N > 1 at C2 size: one JSON line from rank 0 with n_gpus = N, a
