@@ -728,12 +728,13 @@ def main():
     valu_achieved = flops_launch / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
     hbm_frac, valu_frac = achieved / HBM_PEAK_GBS, valu_achieved / valu_peak
     # what the kernel issues for it (tile plans): FMA wave-instructions = 2 sides x nnz x 2 KL / (64 / LPC) lane
-    # groups per wave; the step slots the plan stores (two nonzeros each) say how many of the executed steps
-    # carry nonzeros; per wave step the f64 paired loop issues ~2 x 2 KL FMAs + 24 other VALU instructions
+    # groups per wave; the nonzero slots the plan stores say how many of the executed step halves carry
+    # nonzeros; per wave step the f64 paired loop issues ~2 x 2 KL FMAs + 24 other VALU instructions
     # (rocprofv3 SQ_INSTS_VALU in profiles/)
     slots = info["entry_slots_cell"] + info["entry_slots_gene"]
     tile = info["chunk_len"] < 0
-    slot_fill = (nnz_local / float(slots)) if (tile and slots) else None
+    # entry_slots_* count stored NONZERO slots (a step slot holds two); both orientations store every nonzero
+    slot_fill = (2.0 * nnz_local / float(slots)) if (tile and slots) else None
     kl, lpc = info["KL"], info["LPC"]
     fma_wave_insts = 4.0 * kl * nnz_local / (64.0 / lpc)
     essential_over_issued = (4.0 * kl) / (4.0 * kl + 24.0) if (tile and args.dtype == "f64") else None

@@ -1168,6 +1168,31 @@ def test_library_rccl_one_rank_equals_plain_steps(amd, oracle, hinted):
         assert_allclose(shard.mean_negative_pois_llh(), want, rtol=1e-11)
 
 
+@only_plans("tile")
+def test_a_new_communicator_drops_the_captured_stretch(amd, oracle, plan_kind):
+    """A captured sharded stretch holds an all-reduce bound to the communicator it was captured with: joining a new
+    communicator (or leaving one) on a live engine must drop the cached graphs, and the same (flags, n) stretch
+    is then captured again with the new one (round-4 advisor finding: replay against a freed communicator)."""
+    from schpf_amd.sharded import NativeShard
+    X = synthetic_counts(3000, 1500, 0.04, seed=3)
+    K, a, c = 12, 0.3, 0.3
+    bp, dp, ref = random_state(oracle, X, K, np.float64, seed=2)
+    with load_shard_engine(amd, X, K, np.float64, ref, a, c, bp, dp) as eng:
+        done = 0
+        for _ in range(3):
+            shard = NativeShard(eng, amd.DeviceCAVI.comm_unique_id(), 0, 1)   # comm_init on the live engine
+            shard.steps(1)
+            shard.steps(4)      # captured (one-rank communicator: the graph is the default)
+            shard.steps(4)      # replayed
+            done += 9
+            for _ in range(9):
+                oracle.cavi_iteration(X.data, X.row, X.col, ref, a, c, bp, dp)
+            compare_state(eng, ref, rtol=1e-10)
+        amd._lib.check(eng._lib.schpf_comm_destroy(eng._h))
+        with pytest.raises(amd._lib.SchpfHipError):
+            eng.steps_sharded(4)                                              # no communicator, no stale graph
+
+
 @only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("graph", ["0", "1"])
