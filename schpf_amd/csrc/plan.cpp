@@ -443,18 +443,21 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     P.row_slots = shape.row_slots;
     int win_rows = shape.win_rows;
     if (shape.ring > 1) {
-        // the only multi-slot schedule shipped is the half-window one (slots refilled AT the epoch
-        // boundary); the asynchronous ring of round 2 lives in the history
-        if (shape.sync_stage != 1) throw std::invalid_argument("multi-slot plans need sync_stage = 1");
+        // multi-slot schedules: the half-window one (1: slots refilled AT the epoch boundary, rows work ahead) and
+        // double-buffered sub-windows (2: the next one copied under the steps, no work ahead; plan.h)
+        if (shape.sync_stage != 1 && shape.sync_stage != 2) throw std::invalid_argument("multi-slot plans need sync_stage = 1 or 2");
+        if (shape.sync_stage == 2 && shape.ring != 2) throw std::invalid_argument("double-buffered plans have two slots");
         if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % 16)
             throw std::invalid_argument("slot_bytes must hold a row and be a multiple of 16");
         P.ring = shape.ring;
-        P.sync_stage = 1;
-        P.look = shape.ring - 1;
+        P.sync_stage = shape.sync_stage;
+        P.look = shape.sync_stage == 2 ? 0 : shape.ring - 1;
         P.slot16 = shape.slot_bytes / 16;
         win_rows = (P.slot16 - 4) / shape.row_slots;   // the last 64 bytes of a slot stay free
     }
     if (win_rows < 1) throw std::invalid_argument("win_rows must be positive");
+    P.single = shape.single;
+    if (P.single && P.look > 0) throw std::invalid_argument("single step counts do not go with the work-ahead schedule");
     if ((int64_t)std::max(P.ring, 1) * std::max<int64_t>(P.slot16, (int64_t)win_rows * shape.row_slots) > 65536)
         throw std::invalid_argument("the LDS window does not fit 16-bit positions");
     P.n_major = n_major;
@@ -711,7 +714,7 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
             for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                 int mx = 0;
                 for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, P.steps[((size_t)b * wpb + v) * W + w]);
-                work += mx + (P.ring > 1 ? 1 : 2);
+                work += (int64_t)tile_stored_steps(P, mx) + (P.ring > 1 ? 1 : 2);
             }
             P.task_work[(size_t)t] = work;
         }
@@ -786,9 +789,10 @@ void tile_plan_report(const TilePlanHost &P)
             }
             barrier_steps += (int64_t)mx * wpb;
         }
-    fprintf(stderr, "[schpf_hip]     nnz %lld, step slots x2 %lld (ELL fill %.3f), barrier-limited wave-steps %lld vs %lld "
-            "(%.3f)\n", (long long)P.nnz, (long long)(wave_steps * gpw * 2),
-            wave_steps ? (double)P.nnz / (double)(wave_steps * gpw * 2) : 0.0, (long long)barrier_steps,
+    const int per_step = P.single ? 1 : 2;   // nonzeros an executed step takes
+    fprintf(stderr, "[schpf_hip]     nnz %lld, executed nonzero slots %lld (ELL fill %.3f), barrier-limited wave-steps %lld vs %lld "
+            "(%.3f)\n", (long long)P.nnz, (long long)(wave_steps * gpw * per_step),
+            wave_steps ? (double)P.nnz / (double)(wave_steps * gpw * per_step) : 0.0, (long long)barrier_steps,
             (long long)wave_steps, wave_steps ? (double)wave_steps / (double)barrier_steps : 0.0);
 }
 
@@ -834,7 +838,8 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     const double t1 = now();
     tile_plan_begin(P, nnz, n_major, n_minor, shape, mptr.data());
     const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb, win_rows = P.win_rows;
-    const bool ring = P.ring > 1;
+    const bool ring = P.ring > 1 && P.look > 0;   // the work-ahead schedule; double-buffered sub-windows build like windows
+    const int per_step = P.single ? 1 : 2;        // nonzeros per counted step
 
     // sorted copies: every later pass walks the rows' runs sequentially
     const int nth = host_threads();
@@ -868,7 +873,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
                         const int64_t bound = ((int64_t)w + 1) * win_rows;   // one division per run, not per nonzero
                         int64_t s = j;
                         while (j < end && s_minor[(size_t)j] < bound) ++j;
-                        const int64_t steps = (j - s + 1) / 2;   // two nonzeros per step
+                        const int64_t steps = (j - s + per_step - 1) / per_step;   // two nonzeros per step (one: single)
                         if (steps > 65535) { err[(size_t)t] = 1; continue; }
                         if (steps > st[w]) st[w] = (uint16_t)steps;
                     }
@@ -926,14 +931,14 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     parallel_for(total_padded * epw, nth, [&](int64_t b, int64_t e, int) {
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
-    // ring mode: an unused step slot must still point at a row that is valid while it is read --
+    // several slots: an unused step slot must still point at a row that is valid while it is read --
     // the first row of the epoch's own slot (count 0: it contributes nothing)
-    if (ring)
+    if (P.ring > 1)
         parallel_for(P.n_blocks * wpb, nth, [&](int64_t bw0, int64_t bw1, int) {
             for (int64_t bw = bw0; bw < bw1; ++bw) {
                 int64_t off = wave_off[(size_t)bw];
                 for (int w = 0; w < W; ++w) {
-                    const int64_t n = (int64_t)P.steps[(size_t)bw * W + w] * gpw;
+                    const int64_t n = tile_stored_steps(P, P.steps[(size_t)bw * W + w]) * gpw;
                     const uint32_t o16 = (uint32_t)(w % P.ring) * (uint32_t)P.slot16;
                     for (int64_t q = off; q < off + n; ++q) {
                         if (packed) P.entries[(size_t)q * 2] = o16 | (o16 << 16);
@@ -1101,7 +1106,8 @@ void balance_windows_host(int64_t nnz, const int32_t *major, const int32_t *mino
                           const TileShape &shape, BigVec<int32_t> &vminor, std::vector<int32_t> &minor_of,
                           BalanceGeometry &geo)
 {
-    if (shape.ring > 1) throw std::invalid_argument("balanced windows need whole windows (ring <= 1)");
+    if (shape.ring > 1 && shape.sync_stage != 2)
+        throw std::invalid_argument("balanced windows need windows without work-ahead (ring <= 1, or double-buffered)");
     // rows -> blocks exactly as the builder will cut them: that depends on the row lengths only
     BigVec<int32_t> order;
     std::vector<int64_t> mptr;

@@ -75,6 +75,8 @@ __global__ void fill_i64_kernel(int64_t n, int64_t v, int64_t *__restrict__ out)
 struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
     int ring, slot16, look;
+    int sched;    // 1: the work-ahead schedule (ring > 1 with look > 0): segments come from ring_schedule_kernel
+    int single;   // steps count nonzeros (plan.h)
 };
 
 // LDS position of minor row m in 16-byte units (plan.h tile_off16)
@@ -114,7 +116,7 @@ __global__ void steps_kernel(Geometry g, int64_t n_slots, const int32_t *__restr
     const int64_t lo = lower_bound_minor(s_minor, r0, r1, (int64_t)w * g.win_rows);
     const int64_t hi = lower_bound_minor(s_minor, lo, r1, ((int64_t)w + 1) * g.win_rows);
     if (hi == lo) return;
-    const int64_t steps = (hi - lo + 1) / 2;
+    const int64_t steps = g.single ? hi - lo : (hi - lo + 1) / 2;
     if (steps > 65535) { *err = 1; return; }
     const int64_t b = slot / g.gpb;
     const int v = (int)(slot % g.gpb) / g.gpw;
@@ -220,7 +222,7 @@ __device__ __forceinline__ void segment_bounds(const Geometry &g, int64_t slot, 
                                                const int32_t *__restrict__ s_minor, const int32_t *__restrict__ start,
                                                int64_t &s, int64_t &e_)
 {
-    if (g.ring > 1) {   // ring mode: what the schedule gave this lane in epoch w
+    if (g.sched) {   // work-ahead schedule: what it gave this lane in epoch w
         const int32_t *st = start + (size_t)slot * ((size_t)g.W + 1);
         s = r0 + st[w];
         e_ = r0 + st[w + 1];
@@ -402,7 +404,8 @@ __global__ void ring_pad_kernel(Geometry g, int64_t n_bw, const int64_t *__restr
     const int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (id >= n_bw * g.W) return;
     const int w = (int)(id % g.W);
-    const int64_t off = win_off[id], n = (int64_t)steps32[id] * g.gpw;
+    const int64_t stored = g.single ? ((int64_t)steps32[id] + 1) / 2 : (int64_t)steps32[id];
+    const int64_t off = win_off[id], n = stored * g.gpw;
     const uint32_t o16 = (uint32_t)(w % g.ring) * (uint32_t)g.slot16;
     for (int64_t q = off; q < off + n; ++q) {
         if (g.packed) entries[(size_t)q * 2] = o16 | (o16 << 16);
@@ -479,7 +482,9 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         g.row_slots = P.row_slots;
         g.ring = P.ring; g.slot16 = P.slot16;
         g.look = P.look;
-        const bool ring = P.ring > 1;
+        const bool ring = P.ring > 1 && P.look > 0;   // the work-ahead schedule; double-buffered sub-windows build like windows
+        g.sched = ring ? 1 : 0;
+        g.single = P.single ? 1 : 0;
         const int64_t n_slots = P.n_blocks * P.gpb;
         Tmp d_rows((size_t)n_slots * 4);
         PD_CHECK(hipMemcpyAsync(d_rows.p, P.block_rows.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, st));
@@ -536,7 +541,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         Tmp d_woff(win_off.size() * 8), d_rank(pass_rank.size() * 4);
         PD_CHECK(hipMemcpyAsync(d_woff.p, win_off.data(), win_off.size() * 8, hipMemcpyHostToDevice, st));
         PD_CHECK(hipMemcpyAsync(d_rank.p, pass_rank.data(), pass_rank.size() * 4, hipMemcpyHostToDevice, st));
-        if (ring && n_steps > 0)
+        if (P.ring > 1 && n_steps > 0)
             hipLaunchKernelGGL(ring_pad_kernel, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, st, g,
                                (int64_t)P.n_blocks * P.wpb, d_woff.as<int64_t>(), d_steps32.as<unsigned>(),
                                static_cast<uint32_t *>(d_entries));
@@ -744,7 +749,8 @@ void balance_windows_device(void *stream, int64_t nnz, const int32_t *d_major, c
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     *d_minor_of = nullptr;
-    if (shape.ring > 1) throw std::invalid_argument("balanced windows need whole windows (ring <= 1)");
+    if (shape.ring > 1 && shape.sync_stage != 2)
+        throw std::invalid_argument("balanced windows need windows without work-ahead (ring <= 1, or double-buffered)");
     const int threads = 256;
     // row lengths -> the blocks the builder will cut (tile_plan_begin depends on the lengths only)
     Tmp d_count((size_t)n_major * 4);

@@ -275,7 +275,7 @@ __device__ __forceinline__ int entry_minor(unsigned off16, int w, int win_rows, 
 }
 template <typename T, int NV, int LPC, bool PACK>
 __device__ __noinline__ void slow_task_row(const void *__restrict__ entries, size_t pos, const uint16_t *__restrict__ st,
-                                           int w0, int w1, int win_rows, int ring, int slot16, int stride,
+                                           int w0, int w1, int win_rows, int ring, int slot16, int single, int stride,
                                            const T *__restrict__ lt_row, const T *__restrict__ log_minor, int sub,
                                            int K, T *__restrict__ out_row, const int *__restrict__ minor_of_block)
 {
@@ -288,7 +288,7 @@ __device__ __noinline__ void slow_task_row(const void *__restrict__ entries, siz
     for (int k = 0; k < KL; ++k) acc[k] = T(0);
 #pragma unroll 1
     for (int w = w0; w < w1; ++w) {
-        const int steps = st[w];
+        const int steps = single ? ((int)st[w] + 1) >> 1 : (int)st[w];   // stored slots; an unused half slot has count 0
 #pragma unroll 1
         for (int p = 0; p < steps; ++p) {
             const typename EF::type ee = EF::load(entries, pos + (size_t)p * stride);
@@ -554,6 +554,19 @@ __device__ __forceinline__ void step_row_load(const T *__restrict__ row, int sub
     load_lane<T, NV, LPC>(row, sub, v);
 }
 
+// LDS-DMA that the compiler does not see (double-buffered sub-windows, plan.h): a 16-byte piece per lane, global ->
+// LDS at lds_addr + 16 * lane.  With the builtin, hipcc orders every later ds_read behind the copy (s_waitcnt vmcnt(0)
+// in front of the first LDS read: the copy would be exposed again) and drains it with the entry loads; an asm
+// statement is neither counted nor waited for -- the kernel waits itself (s_waitcnt vmcnt(0) in front of the
+// sub-window's barrier).  Vector-memory loads return in order, so the compiler's own counted waits on the entry
+// loads stay sufficient: they can only wait for more than they name.  M0 is saved and restored (compiler-reserved).
+__device__ __forceinline__ void hidden_dma16(const void *gsrc, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+
 // the minor row an entry points at: LDS position in 16-byte units
 template <typename T> __device__ __forceinline__ const T *lds_row(const unsigned char *lds, unsigned off16)
 {
@@ -622,6 +635,14 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     // live through the step loop), and handed to the copying lanes by ds_bpermute -- no load in front of the copies
     constexpr int ROW_SLOTS = KP * (int)sizeof(T) / 16;
     constexpr int RPI = 64 / ROW_SLOTS;     // whole rows per copy instruction
+    // double-buffered sub-windows (plan.h): the copies of sub-window w + 1 run under the steps of w, hidden from the compiler
+    const bool db = a.sync_stage == 2;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
+    auto copy16 = [&](const unsigned char *gsrc, unsigned char *dst) {   // dst: wave-uniform, the lane's piece lands at dst + 16 * lane
+        if (db) hidden_dma16(gsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(dst - lds_raw))));
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
     const int rpw = BAL ? (a.win_rows + a.wpb - 1) / a.wpb : 0;
     const bool rows_ahead = BAL && rpw <= 128;
     int rows_lo = -1, rows_hi = -1;
@@ -653,9 +674,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                     row = src < 64 ? row : hi;
                 }
                 if (rr < RPI && src < rpw && row >= 0)
-                    __builtin_amdgcn_global_load_lds(
-                        (const __attribute__((address_space(1))) void *)(tab + ((size_t)row * ROW_SLOTS + q) * 16),
-                        (__attribute__((address_space(3))) void *)(dst + (size_t)u * RPI * ROW_SLOTS * 16), 16, 0, 0);
+                    copy16(tab + ((size_t)row * ROW_SLOTS + q) * 16, dst + (size_t)u * RPI * ROW_SLOTS * 16);
             }
             return;
         }
@@ -684,9 +703,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 for (int u = 0; u < BATCH; ++u) {
                     const int i = i0 + u * a.wpb;
                     if (i < n_inst && row[u] >= 0)
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void *)(tab + ((size_t)row[u] * ROW_SLOTS + q) * 16),
-                            (__attribute__((address_space(3))) void *)(dst + (size_t)i * RPI * ROW_SLOTS * 16), 16, 0, 0);
+                        copy16(tab + ((size_t)row[u] * ROW_SLOTS + q) * 16, dst + (size_t)i * RPI * ROW_SLOTS * 16);
                 }
             }
             return;
@@ -696,17 +713,28 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         const int nbytes = nr * KP * (int)sizeof(T);                  // a multiple of 16
         for (int off = wv * 1024; off < nbytes; off += a.wpb * 1024) {   // scalar loop
             const int o = off + lane * 16;
-            if (o < nbytes)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
-                                                 (__attribute__((address_space(3))) void *)(dst + off), 16, 0, 0);
+            if (o < nbytes) copy16(src + o, dst + off);
         }
     };
     // Window schedule: the whole LDS is window w, refilled between two barriers.  Half-window
     // schedule (a.ring slots, plan.h): the first epoch fills every slot, a later one only the slot
     // that the last epoch's own sub-window had.
+    // Double-buffered sub-windows: sub-window w + 1 is copied into the other slot under the steps of w; before the
+    // barrier that opens w every wave waits for its own copies (the compiler knows nothing of them)
     const int L = a.ring > 1 ? a.ring : 1;
+    if (db && MODE != MODE_RANDOM) {   // the workgroup's previous task is behind a barrier (the task loops)
+        stage(w0, w0 & 1);
+        if (BAL && w0 + 1 < w1) fetch_rows(w0 + 1);
+    }
     for (int w = w0; w < w1; ++w) {
-        if (MODE != MODE_RANDOM) {
+        if (MODE != MODE_RANDOM && db) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // sub-window w has landed, w - 1 is fully consumed
+            if (w + 1 < w1 && (SCHPF_ABLATE != 3)) {
+                stage(w + 1, (w + 1) & 1);
+                if (BAL && w + 2 < w1) fetch_rows(w + 2);
+            }
+        } else if (MODE != MODE_RANDOM) {
             __syncthreads();                       // previous window fully consumed
             const int sw0 = (L == 1 || w == w0) ? w : w + L - 1;
             const int sw1 = min(w + L, w1);
@@ -715,13 +743,16 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             __syncthreads();
             if (BAL && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
         }
+        // stored step slots of this (wave, window); `single`: steps counts nonzeros, an odd count leaves the second
+        // half of its last slot unexecuted in the one-nonzero-at-a-time loop (elsewhere that half has count 0)
+        const int nsl = a.single ? (steps + 1) >> 1 : steps;
         if (PIPE) {
             // Rolling LDS pipeline, one nonzero deep: the minor rows of step p+1 are fetched from the
             // window while step p is still being computed -- row A' right after nonzero A has been
             // consumed, into the same registers, then the same for B.  A wave never starts a step
             // by waiting a full LDS latency (measured: the unpipelined loop overlapped the LDS read
             // phase and the FMA phase of the 4 waves of a SIMD poorly).
-            if (steps > 0) {   // prologue: the first step's rows (the ring was primed before the barrier)
+            if (nsl > 0) {   // prologue: the first step's rows (the ring was primed before the barrier)
                 const E c = ring[0];
                 unsigned i0 = EF::idx(c, 0), i1 = EF::idx(c, 1);
                 xc[0][0] = EF::val(c, 0); xc[0][1] = EF::val(c, 1);
@@ -798,20 +829,32 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             // body the compiler gave the row registers different homes on different paths and paid for it with
             // 10 v_mov_b32 per step in the float32 kernel (hipcc -S; 16 % of its VALU instructions)
             int p = 0;
-            for (; p + RING <= steps; p += RING) {
+            if (db) {
+                // the first turn of a double-buffered sub-window on its own: here the compiler knows that the ring is
+                // complete (it was primed before the barrier) and waits for nothing until the turn's own refills come
+                // round -- inside the loop below its counted waits would stand in front of the first steps and, because
+                // loads return in order, wait for the copies of the next sub-window that were issued just above
+#define SCHPF_PIPE_STEP(I)                                                                              \
+    ring[I] = EF::load(a.entries, pos + (size_t)(I + RING) * GPW);                                      \
+    if (I < nsl) pipe_step(std::integral_constant<int, I>{});
+                SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
+#undef SCHPF_PIPE_STEP
+                p = RING;
+            }
+            for (; p + RING <= nsl; p += RING) {
 #define SCHPF_PIPE_STEP(I)                                                                              \
     if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
     pipe_step(std::integral_constant<int, I>{});
                 SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
 #undef SCHPF_PIPE_STEP
             }
-            if (p < steps) {
+            if (p < nsl) {
                 // the ragged turn: slot i was decoded one step ago: refill it; decode the NEXT step's slot.  Past
                 // the window's last step that is the next window's entry or padding: its indices are in range, the
                 // rows read with them are never used
 #define SCHPF_PIPE_STEP(I)                                                                              \
     if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
-    if (p + I < steps) pipe_step(std::integral_constant<int, I>{});
+    if (p + I < nsl) pipe_step(std::integral_constant<int, I>{});
                 SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
 #undef SCHPF_PIPE_STEP
             }
@@ -825,7 +868,8 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             // underflowed s poisons the group's accumulators (inf / NaN), which is detected once after the task.
             typedef typename Vec16<T>::type V16;
             unsigned second = 0;   // LDS position of the current step's second row
-            if (steps > 0) {       // prologue: the first step's first row (the ring was primed before the barrier)
+            const int nz = a.single ? steps : 2 * steps;   // nonzeros (slot halves) this wave executes in the window
+            if (nsl > 0) {         // prologue: the first step's first row (the ring was primed before the barrier)
                 const E c = ring[0];
                 unsigned i0 = EF::idx(c, 0);
                 second = EF::idx(c, 1);
@@ -864,23 +908,35 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 second = n1;
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // the last slot of an odd count (`single`): its first nonzero only
+            auto roll_half = [&](auto I_) {
+                constexpr int I = decltype(I_)::value;
+                roll_nonzero((T)xc[I & 1][0], second);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // a turn with guards: slot p + I holds the nonzeros 2 (p + I) and 2 (p + I) + 1 of the wave's nz
+#define SCHPF_ROLL_GUARDED(I)                                                        \
+    ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
+    if (2 * (p + I) + 1 < nz) roll_step(std::integral_constant<int, I>{});           \
+    else if (2 * (p + I) < nz) roll_half(std::integral_constant<int, I>{});
             int p = 0;
-            for (; p + RING <= steps; p += RING) {
+            if (db) {   // the first turn on its own: see the paired loop
+                SCHPF_ROLL_GUARDED(0) SCHPF_ROLL_GUARDED(1) SCHPF_ROLL_GUARDED(2) SCHPF_ROLL_GUARDED(3)
+                p = RING;
+            }
+            for (; 2 * (p + RING) <= nz; p += RING) {
 #define SCHPF_ROLL_STEP(I)                                                           \
     ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
     roll_step(std::integral_constant<int, I>{});
                 SCHPF_ROLL_STEP(0) SCHPF_ROLL_STEP(1) SCHPF_ROLL_STEP(2) SCHPF_ROLL_STEP(3)
 #undef SCHPF_ROLL_STEP
             }
-            if (p < steps) {
-#define SCHPF_ROLL_STEP(I)                                                           \
-    ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
-    if (p + I < steps) roll_step(std::integral_constant<int, I>{});
-                SCHPF_ROLL_STEP(0) SCHPF_ROLL_STEP(1) SCHPF_ROLL_STEP(2) SCHPF_ROLL_STEP(3)
-#undef SCHPF_ROLL_STEP
+            if (2 * p < nz) {
+                SCHPF_ROLL_GUARDED(0) SCHPF_ROLL_GUARDED(1) SCHPF_ROLL_GUARDED(2) SCHPF_ROLL_GUARDED(3)
             }
+#undef SCHPF_ROLL_GUARDED
         } else
-        for (int p = 0; p < steps; p += RING) {
+        for (int p = 0; p < nsl; p += RING) {
 #pragma unroll
             for (int i = 0; i < RING; ++i) {
                 const E c = ring[i];
@@ -890,7 +946,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 // the refill lands in other registers and the loop needs copies behind a vmcnt(0))
                 asm volatile("" : "+v"(i0), "+v"(i1), "+v"(xf0), "+v"(xf1));
                 ring[i] = EF::load(a.entries, pos + (size_t)(p + i + RING) * GPW);   // may run past: padded
-                if (p + i < steps) {                                   // scalar branch
+                if (p + i < nsl) {                                     // scalar branch
                     if (MODE == MODE_RANDOM) {
                         // t = 0 responsibilities (reference scHPF_.py:652-655), counter-based draws
 #pragma unroll 1
@@ -941,7 +997,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 }
             }
         }
-        pos += (size_t)steps * GPW;
+        pos += (size_t)nsl * GPW;
         if (w + 1 < w1) {   // prime the ring for the next window before its staging barrier
             steps = __builtin_amdgcn_readfirstlane((int)st[w + 1]);
 #pragma unroll
@@ -966,7 +1022,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     }
     if (MODE == MODE_PHI && __builtin_expect(any_bad && live, 0)) {   // group-uniform; rare: see slow_nonzero
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
-                                        a.win_rows, a.ring, a.slot_bytes / 16, GPW, a.log_major + (size_t)major * KP,
+                                        a.win_rows, a.ring, a.slot_bytes / 16, a.single, GPW, a.log_major + (size_t)major * KP,
                                         a.log_minor, sub, a.K, out_row,
                                         BAL ? a.minor_of + (size_t)blk * a.n_virtual : nullptr);
         return;
