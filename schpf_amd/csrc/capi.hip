@@ -678,7 +678,7 @@ template <typename T> struct Engine final : schpf_ctx {
             bool presorted = side == 0 ? rc_sorted : cr_sorted;
             const int32_t *d_major = side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>();
             const int32_t *d_minor = side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>();
-            const schpf::TileShape &sh = side == 0 ? sh_c : sh_g;
+            schpf::TileShape sh = side == 0 ? sh_c : sh_g;
             int n_minor_plan = side == 0 ? G : N;
             DevBuf vminor;
             td.minor_of.release(); td.n_virtual = 0;
@@ -707,7 +707,11 @@ template <typename T> struct Engine final : schpf_ctx {
                     d_minor = vminor.as<int32_t>();
                     n_minor_plan = geo.n_virtual;
                     presorted = false;
-                } else vminor.release();
+                } else {
+                    vminor.release();
+                    // the double-buffered kernels are balanced ones: this side goes back to the schedule it would have had
+                    if (sh.sync_stage == 2) sh = tile_shape(side == 0 ? N : G, side == 0 ? G : N, side == 1, ranges[side], half[side], false);
+                }
                 if (env_int("SCHPF_VERBOSE", 0))
                     fprintf(stderr, "[schpf_hip]   balanced windows, side %d: %d sections of %d windows, %.3f s\n", side,
                             geo.n_sections, geo.D, now_s() - tb);
@@ -886,7 +890,7 @@ template <typename T> struct Engine final : schpf_ctx {
     bool db_now = false;
     bool db_schedule() const { return db_now; }
     schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false, int ranges = 0,
-                                int force_half = -1) const
+                                int force_half = -1, bool allow_db = true) const
     {
         int wpb, lds_kb;
         pick_workgroup(n_major, n_minor, wpb, lds_kb);
@@ -925,7 +929,7 @@ template <typename T> struct Engine final : schpf_ctx {
         // SCHPF_HALF = 0 / slots overrides.
         // Double-buffered sub-windows (plan.h, round 5): two slots of half a window, the next sub-window copied under
         // the steps of the current one.  SCHPF_DB = 1 / 0 forces it on / off (the 1024-thread workgroup only).
-        const bool want_db = db_schedule() && wpb >= 12;
+        const bool want_db = db_schedule() && allow_db && wpb >= 12;
         // one-nonzero-at-a-time kernels (sweep_impl.h ROLL: float64 rows wider than 96 bytes per lane) count their
         // steps in nonzeros wherever rows do not work ahead
         const bool roll_kernel = sizeof(T) == 8 && (size_t)KL * sizeof(T) > 96 && wpb >= 12;
@@ -1103,7 +1107,7 @@ template <typename T> struct Engine final : schpf_ctx {
             const bool sparse = per_row_cell < 24.0 && per_row_gene < 24.0 && (double)G > 2.0 * win && (double)N > 2.0 * win;
             // Double-buffered sub-windows (plan.h; SCHPF_DB=1 / 0): they have no work-ahead, so they go with the balancing
             const int db_env = env_int("SCHPF_DB", -1);
-            db_now = (db_env < 0 ? false : db_env != 0) && want_tile && !want_rows && !transient;
+            db_now = (db_env < 0 ? false : db_env != 0) && want_tile && !want_rows && !transient && forced != 0;
             balance_now = (forced < 0 ? (sparse || db_now) : forced != 0) && want_tile && !want_rows && !transient;
         }
         EarlyIndexCopy early;

@@ -474,6 +474,7 @@ template <> struct TileEntry<true> {      // {idx0 | idx1 << 16, cnt0 | cnt1 << 
         const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(base) + i);
         return make_uint2(v.x, v.y);
     }
+    static __device__ __forceinline__ void touch(const uint2 &e) { asm volatile("" :: "v"(e.x), "v"(e.y)); }
     static __device__ __forceinline__ unsigned idx(const uint2 &e, int u) { return u ? e.x >> 16 : e.x & 0xFFFFu; }
     static __device__ __forceinline__ float val(const uint2 &e, int u) { return (float)(u ? e.y >> 16 : e.y & 0xFFFFu); }
 };
@@ -483,6 +484,7 @@ template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
     {
         return stream_load(reinterpret_cast<const uint4 *>(base) + i);
     }
+    static __device__ __forceinline__ void touch(const uint4 &e) { asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w)); }
     static __device__ __forceinline__ unsigned idx(const uint4 &e, int u) { return u ? e.z : e.x; }
     static __device__ __forceinline__ float val(const uint4 &e, int u) { return __uint_as_float(u ? e.w : e.y); }
 };
@@ -573,9 +575,11 @@ template <typename T> __device__ __forceinline__ const T *lds_row(const unsigned
     return reinterpret_cast<const T *>(lds + (off16 << 4));
 }
 
-// BAL: balanced windows (plan.h) -- an instantiation of its own (1024-thread workgroups only), so that the row-list
+// BAL: 1 = balanced windows (plan.h), 2 = balanced AND double-buffered sub-windows (plan.h, round 5: the schedule is a
+// compile-time fact so that the compiler's wait-count bookkeeping of one schedule does not leak into the other where
+// their paths join) -- instantiations of their own (1024-thread workgroups only), so that the row-list
 // staging costs the kernels of index-cut windows neither registers nor instructions
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, int BAL = 0>
 __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, const int task)
 {
     typedef TileEntry<PACK> EF;
@@ -636,15 +640,16 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     constexpr int ROW_SLOTS = KP * (int)sizeof(T) / 16;
     constexpr int RPI = 64 / ROW_SLOTS;     // whole rows per copy instruction
     // double-buffered sub-windows (plan.h): the copies of sub-window w + 1 run under the steps of w, hidden from the compiler
-    const bool db = a.sync_stage == 2;
+    constexpr bool db = BAL == 2;
+    constexpr bool BALANCED = BAL != 0;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
     auto copy16 = [&](const unsigned char *gsrc, unsigned char *dst) {   // dst: wave-uniform, the lane's piece lands at dst + 16 * lane
         if (db) hidden_dma16(gsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(dst - lds_raw))));
         else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                               (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    const int rpw = BAL ? (a.win_rows + a.wpb - 1) / a.wpb : 0;
-    const bool rows_ahead = BAL && rpw <= 128;
+    const int rpw = BALANCED ? (a.win_rows + a.wpb - 1) / a.wpb : 0;
+    const bool rows_ahead = BALANCED && rpw <= 128;
     int rows_lo = -1, rows_hi = -1;
     auto fetch_rows = [&](int sw) {
         if (!rows_ahead) return;
@@ -655,11 +660,11 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         rows_lo = (lane < rpw && l < nr) ? list[l] : -1;
         rows_hi = (lane + 64 < rpw && l + 64 < nr) ? list[l + 64] : -1;
     };
-    if (BAL && MODE != MODE_RANDOM) fetch_rows(w0);
+    if (BALANCED && MODE != MODE_RANDOM) fetch_rows(w0);
     auto stage = [&](int sw, int slot) {
         const int r0 = sw * a.win_rows;
         const int nr = min(a.win_rows, a.n_minor - r0);
-        if (BAL && rows_ahead) {
+        if (BALANCED && rows_ahead) {
             // a wave instruction copies RPI whole rows (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS
             // side of the DMA is base + 16 * lane, so rows land back to back)
             const int rr = lane / ROW_SLOTS, q = lane - rr * ROW_SLOTS;
@@ -678,7 +683,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             }
             return;
         }
-        if constexpr (BAL) {
+        if constexpr (BALANCED) {
             // (very narrow rows: more than 128 rows per wave) the row numbers of a batch of copy instructions are
             // fetched in the staging itself, then the copies go out.  A wave instruction copies RPI whole rows
             // (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS side of the DMA is base + 16 * lane,
@@ -724,15 +729,20 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     const int L = a.ring > 1 ? a.ring : 1;
     if (db && MODE != MODE_RANDOM) {   // the workgroup's previous task is behind a barrier (the task loops)
         stage(w0, w0 & 1);
-        if (BAL && w0 + 1 < w1) fetch_rows(w0 + 1);
+        if (BALANCED && w0 + 1 < w1) fetch_rows(w0 + 1);
     }
     for (int w = w0; w < w1; ++w) {
         if (MODE != MODE_RANDOM && db) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... which also completed the entry ring primed for this sub-window: say so to the compiler (a use of the
+            // registers makes it wait here, for nothing, instead of in front of the first steps -- where its counted wait
+            // would stand behind the copies issued below)
+#pragma unroll
+            for (int i = 0; i < RING; ++i) EF::touch(ring[i]);
             __syncthreads();                       // sub-window w has landed, w - 1 is fully consumed
             if (w + 1 < w1 && (SCHPF_ABLATE != 3)) {
                 stage(w + 1, (w + 1) & 1);
-                if (BAL && w + 2 < w1) fetch_rows(w + 2);
+                if (BALANCED && w + 2 < w1) fetch_rows(w + 2);
             }
         } else if (MODE != MODE_RANDOM) {
             __syncthreads();                       // previous window fully consumed
@@ -741,7 +751,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             if (SCHPF_ABLATE != 3 || w == w0)
             for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
-            if (BAL && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
+            if (BALANCED && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
         }
         // stored step slots of this (wave, window); `single`: steps counts nonzeros, an odd count leaves the second
         // half of its last slot unexecuted in the one-nonzero-at-a-time loop (elsewhere that half has count 0)
@@ -908,17 +918,10 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 second = n1;
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // the last slot of an odd count (`single`): its first nonzero only
-            auto roll_half = [&](auto I_) {
-                constexpr int I = decltype(I_)::value;
-                roll_nonzero((T)xc[I & 1][0], second);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            // a turn with guards: slot p + I holds the nonzeros 2 (p + I) and 2 (p + I) + 1 of the wave's nz
+            // a turn with guards: slot p + I holds the nonzeros 2 (p + I) and 2 (p + I) + 1 of the wave's nz; whole slots only
 #define SCHPF_ROLL_GUARDED(I)                                                        \
     ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
-    if (2 * (p + I) + 1 < nz) roll_step(std::integral_constant<int, I>{});           \
-    else if (2 * (p + I) < nz) roll_half(std::integral_constant<int, I>{});
+    if (2 * (p + I) + 1 < nz) roll_step(std::integral_constant<int, I>{});
             int p = 0;
             if (db) {   // the first turn on its own: see the paired loop
                 SCHPF_ROLL_GUARDED(0) SCHPF_ROLL_GUARDED(1) SCHPF_ROLL_GUARDED(2) SCHPF_ROLL_GUARDED(3)
@@ -931,10 +934,18 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 SCHPF_ROLL_STEP(0) SCHPF_ROLL_STEP(1) SCHPF_ROLL_STEP(2) SCHPF_ROLL_STEP(3)
 #undef SCHPF_ROLL_STEP
             }
-            if (2 * p < nz) {
+            if (2 * p + 1 < nz) {
                 SCHPF_ROLL_GUARDED(0) SCHPF_ROLL_GUARDED(1) SCHPF_ROLL_GUARDED(2) SCHPF_ROLL_GUARDED(3)
             }
 #undef SCHPF_ROLL_GUARDED
+            // an odd count (`single`): the first nonzero of slot nz / 2 alone.  Its row is in the buffer (the last whole
+            // slot's second nonzero, or the prologue, fetched it), its count was decoded into the register pair of the
+            // slot's parity; the row fetched behind it is never used
+            if (nz & 1) {
+                const float xl = ((nz >> 1) & 1) ? xc[1][0] : xc[0][0];
+                roll_nonzero((T)xl, second);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else
         for (int p = 0; p < nsl; p += RING) {
 #pragma unroll
@@ -1024,7 +1035,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
                                         a.win_rows, a.ring, a.slot_bytes / 16, a.single, GPW, a.log_major + (size_t)major * KP,
                                         a.log_minor, sub, a.K, out_row,
-                                        BAL ? a.minor_of + (size_t)blk * a.n_virtual : nullptr);
+                                        BALANCED ? a.minor_of + (size_t)blk * a.n_virtual : nullptr);
         return;
     }
     if (MODE == MODE_PHI) {
@@ -1036,7 +1047,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 }
 
 
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, int BAL = 0>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
     tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK, BAL>(a, task);
@@ -1044,7 +1055,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
 
 // launch slot -> task: longest tasks first (plan.h task_order), so the launch has a short tail
 // a.queue: persistent workgroups, as in tile_sweep_dual_kernel below
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, int BAL = 0>
 __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
     __shared__ int next_slot;
@@ -1075,7 +1086,7 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 // longest-first list is balanced by who is free, not by the dispatcher's round-robin.  queue[1]
 // counts the workgroups that have found the list empty; the last one zeroes both words for the
 // next launch.
-template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, int BAL = 0>
 __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
                                                               const int *__restrict__ order, int n_slots,
                                                               int *__restrict__ queue)
@@ -1116,7 +1127,7 @@ static inline bool lds_opt_in_pending(std::atomic<uint64_t> &raised)
     return (raised.fetch_or(bit) & bit) == 0;
 }
 
-template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, int BAL = 0>
 static hipError_t launch_tile_b(const TileArgs<T> &a_in, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
 {
@@ -1153,14 +1164,19 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
     if (threads <= 512)
         return packed ? launch_tile_b<T, NV, LPC, 512, true>(a, mode, n_tasks, threads, lds_bytes, st)
                       : launch_tile_b<T, NV, LPC, 512, false>(a, mode, n_tasks, threads, lds_bytes, st);
+    // double-buffered sub-windows come with the balancing (capi.hip falls back to another schedule when it cannot balance)
+    if (a.sync_stage == 2 && !a.minor_of) return hipErrorInvalidValue;
+    if (a.sync_stage == 2 && mode != MODE_RANDOM)
+        return packed ? launch_tile_b<T, NV, LPC, 1024, true, 2>(a, mode, n_tasks, threads, lds_bytes, st)
+                      : launch_tile_b<T, NV, LPC, 1024, false, 2>(a, mode, n_tasks, threads, lds_bytes, st);
     if (a.minor_of && mode != MODE_RANDOM)   // balanced windows: capi.hip builds them for 1024-thread workgroups only
-        return packed ? launch_tile_b<T, NV, LPC, 1024, true, true>(a, mode, n_tasks, threads, lds_bytes, st)
-                      : launch_tile_b<T, NV, LPC, 1024, false, true>(a, mode, n_tasks, threads, lds_bytes, st);
+        return packed ? launch_tile_b<T, NV, LPC, 1024, true, 1>(a, mode, n_tasks, threads, lds_bytes, st)
+                      : launch_tile_b<T, NV, LPC, 1024, false, 1>(a, mode, n_tasks, threads, lds_bytes, st);
     return packed ? launch_tile_b<T, NV, LPC, 1024, true>(a, mode, n_tasks, threads, lds_bytes, st)
                   : launch_tile_b<T, NV, LPC, 1024, false>(a, mode, n_tasks, threads, lds_bytes, st);
 }
 
-template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, int BAL = 0>
 static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
                                 int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
 {
@@ -1189,9 +1205,14 @@ static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, co
         return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
                       : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     if ((a0.minor_of != nullptr) != (a1.minor_of != nullptr)) return hipErrorInvalidValue;   // both plans balanced, or neither
+    if ((a0.sync_stage == 2) != (a1.sync_stage == 2)) return hipErrorInvalidValue;           // ... and on one schedule
+    if (a0.sync_stage == 2 && !a0.minor_of) return hipErrorInvalidValue;
+    if (a0.sync_stage == 2)
+        return packed ? launch_dual_b<T, NV, LPC, 1024, true, 2>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                      : launch_dual_b<T, NV, LPC, 1024, false, 2>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     if (a0.minor_of)
-        return packed ? launch_dual_b<T, NV, LPC, 1024, true, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
-                      : launch_dual_b<T, NV, LPC, 1024, false, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
+        return packed ? launch_dual_b<T, NV, LPC, 1024, true, 1>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                      : launch_dual_b<T, NV, LPC, 1024, false, 1>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
                   : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
 }
