@@ -678,11 +678,11 @@ template <typename T> struct Engine final : schpf_ctx {
             bool presorted = side == 0 ? rc_sorted : cr_sorted;
             const int32_t *d_major = side == 0 ? d_row.as<int32_t>() : d_col.as<int32_t>();
             const int32_t *d_minor = side == 0 ? d_col.as<int32_t>() : d_row.as<int32_t>();
-            schpf::TileShape sh = side == 0 ? sh_c : sh_g;
+            const schpf::TileShape &sh = side == 0 ? sh_c : sh_g;
             int n_minor_plan = side == 0 ? G : N;
             DevBuf vminor;
             td.minor_of.release(); td.n_virtual = 0;
-            if (balance_now && (sh.ring <= 1 || sh.sync_stage == 2) && sh.waves_per_block >= 12) {   // the balanced kernels are 1024-thread ones
+            if (balance_now && sh.ring <= 1 && sh.waves_per_block >= 12) {   // the balanced kernels are 1024-thread ones
                 const double tb = now_s();
                 schpf::BalanceGeometry geo;
                 void *mo = nullptr;
@@ -707,11 +707,7 @@ template <typename T> struct Engine final : schpf_ctx {
                     d_minor = vminor.as<int32_t>();
                     n_minor_plan = geo.n_virtual;
                     presorted = false;
-                } else {
-                    vminor.release();
-                    // the double-buffered kernels are balanced ones: this side goes back to the schedule it would have had
-                    if (sh.sync_stage == 2) sh = tile_shape(side == 0 ? N : G, side == 0 ? G : N, side == 1, ranges[side], half[side], false);
-                }
+                } else vminor.release();
                 if (env_int("SCHPF_VERBOSE", 0))
                     fprintf(stderr, "[schpf_hip]   balanced windows, side %d: %d sections of %d windows, %.3f s\n", side,
                             geo.n_sections, geo.D, now_s() - tb);
@@ -856,7 +852,7 @@ template <typename T> struct Engine final : schpf_ctx {
             blocks[s] = ((int64_t)n_maj[s] + (64 / LPC) * wpb - 1) / ((64 / LPC) * wpb);
             half_windows[s] = ((int64_t)n_min[s] + half_rows - 1) / half_rows;
             const double per_row = (double)nnz / std::max(1, n_maj[s]) * (double)half_rows / std::max(1, n_min[s]);
-            half_ok[s] = db_now || (half_env != 0 && per_row >= 16.0 && !balance_now);   // double-buffered: sub-windows always
+            half_ok[s] = half_env != 0 && per_row >= 16.0 && !balance_now;
             partial_seconds[s] = 2.0 * (double)n_maj[s] * (double)row_bytes / 3.5e12;
         }
         const int resident = n_cu();
@@ -873,7 +869,7 @@ template <typename T> struct Engine final : schpf_ctx {
         const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, share, (double)nnz, resident,
                                                                1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
                                                                partial_seconds,
-                                                               db_now ? 0 : (expect_sharded ? 4 : 6), balance_now ? 1.0 : 1.12, 32, expect_sharded,
+                                                               expect_sharded ? 4 : 6, balance_now ? 1.0 : 1.12, 32, expect_sharded,
                                                                env_int("SCHPF_TAPER", 30) / 100.0);
         if (c.ranges[0] <= 0 || c.ranges[1] <= 0) return false;
         for (int s = 0; s < 2; ++s) { ranges[s] = c.ranges[s]; half[s] = c.half[s] ? 1 : 0; }
@@ -886,11 +882,8 @@ template <typename T> struct Engine final : schpf_ctx {
                     c.seconds * 1e3);
         return true;
     }
-    // double-buffered sub-windows for this upload?  (decided per upload, like the balancing)
-    bool db_now = false;
-    bool db_schedule() const { return db_now; }
     schpf::TileShape tile_shape(int n_major, int n_minor, bool gene_side = false, int ranges = 0,
-                                int force_half = -1, bool allow_db = true) const
+                                int force_half = -1) const
     {
         int wpb, lds_kb;
         pick_workgroup(n_major, n_minor, wpb, lds_kb);
@@ -927,23 +920,10 @@ template <typename T> struct Engine final : schpf_ctx {
         //    half of C3's cells 4 / 8: the cell side +1..4 % with it; 1/8: +2 %), >= 4 in the two-launch
         //    iteration of a row shard (1/8 of C3: sweeps 2 x 70 -> 2 x 63 us).
         // SCHPF_HALF = 0 / slots overrides.
-        // Double-buffered sub-windows (plan.h, round 5): two slots of half a window, the next sub-window copied under
-        // the steps of the current one.  SCHPF_DB = 1 / 0 forces it on / off (the 1024-thread workgroup only).
-        const bool want_db = db_schedule() && allow_db && wpb >= 12;
         // one-nonzero-at-a-time kernels (sweep_impl.h ROLL: float64 rows wider than 96 bytes per lane) count their
         // steps in nonzeros wherever rows do not work ahead
         const bool roll_kernel = sizeof(T) == 8 && (size_t)KL * sizeof(T) > 96 && wpb >= 12;
         sh.single = roll_kernel && env_int("SCHPF_SINGLE", 1) != 0;
-        if (want_db) {
-            const int slot_bytes = (int)((size_t)lds_kb * 1024 / 2 / 16 * 16);
-            const int64_t sub_rows = ((int64_t)slot_bytes - 64) / (int64_t)row_bytes;
-            if (sub_rows >= 1) {
-                sh.ring = 2;
-                sh.sync_stage = 2;
-                sh.slot_bytes = slot_bytes;
-                sh.win_rows = (int)sub_rows;
-            }
-        } else
         {
             const int half_env = env_int("SCHPF_HALF", -1);
             int n_slots = half_env >= 2 ? half_env : 0;
@@ -998,7 +978,7 @@ template <typename T> struct Engine final : schpf_ctx {
         auto build_host = [&](const int32_t *major, const int32_t *minor, int n_major, int n_minor, const schpf::TileShape &sh,
                               TileDev &td, std::vector<int32_t> &mo) {
             td.n_virtual = 0;
-            if (balance_now && (sh.ring <= 1 || sh.sync_stage == 2) && sh.waves_per_block >= 12) {
+            if (balance_now && sh.ring <= 1 && sh.waves_per_block >= 12) {
                 schpf::BigVec<int32_t> vminor;
                 schpf::BalanceGeometry geo;
                 schpf::balance_windows_host(nnz, major, minor, n_major, n_minor, sh, vminor, mo, geo);
@@ -1105,10 +1085,7 @@ template <typename T> struct Engine final : schpf_ctx {
             const double per_row_cell = (double)nnz_ / std::max(1, N) * std::min(1.0, win / std::max(1, G));
             const double per_row_gene = (double)nnz_ / std::max(1, G) * std::min(1.0, win / std::max(1, N));
             const bool sparse = per_row_cell < 24.0 && per_row_gene < 24.0 && (double)G > 2.0 * win && (double)N > 2.0 * win;
-            // Double-buffered sub-windows (plan.h; SCHPF_DB=1 / 0): they have no work-ahead, so they go with the balancing
-            const int db_env = env_int("SCHPF_DB", -1);
-            db_now = (db_env < 0 ? false : db_env != 0) && want_tile && !want_rows && !transient && forced != 0;
-            balance_now = (forced < 0 ? (sparse || db_now) : forced != 0) && want_tile && !want_rows && !transient;
+            balance_now = (forced < 0 ? sparse : forced != 0) && want_tile && !want_rows && !transient;
         }
         EarlyIndexCopy early;
         const bool device_plans = want_tile && env_int("SCHPF_DEVICE_PLAN", 1);
@@ -2062,9 +2039,8 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         sh.lpc = lpc; sh.waves_per_block = waves_per_block; sh.win_rows = win_rows; sh.target_tasks = target_tasks;
         sh.row_slots = env_int("SCHPF_DEBUG_ROW_SLOTS", 10);   // 160-byte table rows
         sh.ring = ring < 0 ? -ring : ring; sh.sync_stage = sh.ring > 1 ? 1 : 0; sh.slot_bytes = slot_bytes;
-        // SCHPF_DEBUG_SYNC_STAGE=2 (with ring 2): double-buffered sub-windows; SCHPF_DEBUG_SINGLE=1: steps count nonzeros
-        if (sh.ring == 2 && env_int("SCHPF_DEBUG_SYNC_STAGE", 1) == 2) sh.sync_stage = 2;
-        sh.single = env_int("SCHPF_DEBUG_SINGLE", 0) != 0;
+        // SCHPF_DEBUG_SINGLE=1: steps count nonzeros (plan.h; window schedule only)
+        sh.single = env_int("SCHPF_DEBUG_SINGLE", 0) != 0 && sh.ring <= 1;
         sh.allow_packed = getenv("SCHPF_PACK") ? atoi(getenv("SCHPF_PACK")) != 0 : true;
         sh.bank_order = env_int("SCHPF_BANK_ORDER", 2);
         sh.taper = env_int("SCHPF_TAPER", 0) / 100.0;
@@ -2073,7 +2049,7 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
         // minor rows and every entry is mapped back through minor_of
         std::vector<int32_t> minor_of;
         schpf::BalanceGeometry geo;
-        const bool balanced = env_int("SCHPF_DEBUG_BALANCE", 0) != 0 && (sh.ring <= 1 || sh.sync_stage == 2);
+        const bool balanced = env_int("SCHPF_DEBUG_BALANCE", 0) != 0 && sh.ring <= 1;
         if (balanced) {
             schpf::BigVec<int32_t> vminor;
             schpf::balance_windows_host(nnz, major, minor, n_major, n_minor, sh, vminor, minor_of, geo);

@@ -45,8 +45,7 @@ template <typename T> struct TileArgs {
     int n_virtual;
     int llh_tab_off;               // MODE_LLH: byte offset in LDS of the logarithm table (behind the window; LlhAccumulator::TABLE_BYTES)
     int ring, slot_bytes;          // ring mode (plan.h): slots in the LDS ring (<= 1: window mode), bytes per slot
-    int sync_stage;                // several slots: 1 = half-window schedule (slots refilled at the epoch boundary),
-                                   // 2 = double-buffered sub-windows (the next one copied under the steps; plan.h)
+    int sync_stage;                // ring mode: half-window schedule (slots refilled at the epoch boundary)
     int single;                    // steps[] count nonzeros, (steps + 1) / 2 slots are stored (plan.h)
     uint64_t seed;                 // MODE_RANDOM
     int major_is_cell;

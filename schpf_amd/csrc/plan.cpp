@@ -443,15 +443,14 @@ void tile_plan_begin(TilePlanHost &P, int64_t nnz, int n_major, int n_minor, con
     P.row_slots = shape.row_slots;
     int win_rows = shape.win_rows;
     if (shape.ring > 1) {
-        // multi-slot schedules: the half-window one (1: slots refilled AT the epoch boundary, rows work ahead) and
-        // double-buffered sub-windows (2: the next one copied under the steps, no work ahead; plan.h)
-        if (shape.sync_stage != 1 && shape.sync_stage != 2) throw std::invalid_argument("multi-slot plans need sync_stage = 1 or 2");
-        if (shape.sync_stage == 2 && shape.ring != 2) throw std::invalid_argument("double-buffered plans have two slots");
+        // the only multi-slot schedule shipped is the half-window one (slots refilled AT the epoch
+        // boundary); the asynchronous ring of round 2 and the double-buffered sub-windows of round 5 live in the history
+        if (shape.sync_stage != 1) throw std::invalid_argument("multi-slot plans need sync_stage = 1");
         if (shape.slot_bytes < 16 * shape.row_slots + 64 || shape.slot_bytes % 16)
             throw std::invalid_argument("slot_bytes must hold a row and be a multiple of 16");
         P.ring = shape.ring;
-        P.sync_stage = shape.sync_stage;
-        P.look = shape.sync_stage == 2 ? 0 : shape.ring - 1;
+        P.sync_stage = 1;
+        P.look = shape.ring - 1;
         P.slot16 = shape.slot_bytes / 16;
         win_rows = (P.slot16 - 4) / shape.row_slots;   // the last 64 bytes of a slot stay free
     }
@@ -838,7 +837,7 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     const double t1 = now();
     tile_plan_begin(P, nnz, n_major, n_minor, shape, mptr.data());
     const int W = P.n_windows, gpb = P.gpb, gpw = P.gpw, wpb = P.wpb, win_rows = P.win_rows;
-    const bool ring = P.ring > 1 && P.look > 0;   // the work-ahead schedule; double-buffered sub-windows build like windows
+    const bool ring = P.ring > 1;
     const int per_step = P.single ? 1 : 2;        // nonzeros per counted step
 
     // sorted copies: every later pass walks the rows' runs sequentially
@@ -931,9 +930,9 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
     parallel_for(total_padded * epw, nth, [&](int64_t b, int64_t e, int) {
         std::memset(P.entries.data() + b, 0, (size_t)(e - b) * sizeof(uint32_t));
     });
-    // several slots: an unused step slot must still point at a row that is valid while it is read --
+    // ring mode: an unused step slot must still point at a row that is valid while it is read --
     // the first row of the epoch's own slot (count 0: it contributes nothing)
-    if (P.ring > 1)
+    if (ring)
         parallel_for(P.n_blocks * wpb, nth, [&](int64_t bw0, int64_t bw1, int) {
             for (int64_t bw = bw0; bw < bw1; ++bw) {
                 int64_t off = wave_off[(size_t)bw];
@@ -1106,8 +1105,7 @@ void balance_windows_host(int64_t nnz, const int32_t *major, const int32_t *mino
                           const TileShape &shape, BigVec<int32_t> &vminor, std::vector<int32_t> &minor_of,
                           BalanceGeometry &geo)
 {
-    if (shape.ring > 1 && shape.sync_stage != 2)
-        throw std::invalid_argument("balanced windows need windows without work-ahead (ring <= 1, or double-buffered)");
+    if (shape.ring > 1) throw std::invalid_argument("balanced windows need whole windows (ring <= 1)");
     // rows -> blocks exactly as the builder will cut them: that depends on the row lengths only
     BigVec<int32_t> order;
     std::vector<int64_t> mptr;

@@ -138,21 +138,15 @@ void build_sweep_plan(int64_t nnz, const int32_t *major, const int32_t *minor, c
 //    window schedule, meets at twice as many barriers, and the kernel is the window kernel with a
 //    different staging range; 0.87 of the slots carry nonzeros at C3 against 0.76.
 //
-//  * DOUBLE-BUFFERED sub-windows (round 5; ring == 2, sync_stage = 2, look = 0): two slots of half a window;
-//    while the workgroup works through sub-window w in slot w % 2, sub-window w + 1 is copied into the other
-//    slot UNDER those steps (LDS-DMA issued from inline assembly, so that the compiler neither drains it in front
-//    of the LDS reads nor counts it among the entry loads; sweep_impl.h), one barrier per sub-window.  No work
-//    ahead: the other slot is not readable while it is being filled, so the steps of a (wave, sub-window) are
-//    those of its fullest row -- which is why this schedule goes with BALANCED windows (below) and, for the
-//    one-nonzero-at-a-time kernels, with `single` step counts.  Builder-wise it is the window schedule with
-//    small windows and LDS positions that carry the slot.
-//
 //  * `single` (round 5): the steps of a (block, wave, window) count NONZEROS, not pairs -- an odd count does
 //    not execute the second half of its last step slot.  Storage is unchanged (two nonzeros per slot,
 //    tile_stored_steps slots per window); for the kernels that take one nonzero at a time (wide rows).
 //
 // (Round 2 also built an ASYNCHRONOUS ring -- five small slots, copies under the compute, no barrier --
-// which was 8-13 % slower; it is not in the product sources any more: DESIGN.md 9, git history.)
+// which was 8-13 % slower, and round 5 DOUBLE-BUFFERED sub-windows -- two slots, the next sub-window copied under the
+// steps by LDS-DMA issued from inline assembly, balanced, one barrier per sub-window -- 10-15 % slower than the
+// schedules above at C3 and at K = 50; neither is in the product sources any more: profiles/HISTORY.md,
+// profiles/r05/ab_double_buffered_windows.txt, commit 3fb3871.)
 struct TilePlanHost {
     int n_major = 0, n_minor = 0;
     int lpc = 4, gpw = 16, wpb = 8, gpb = 128;   // lanes/group, groups/wave, waves/block, groups/block
@@ -161,7 +155,7 @@ struct TilePlanHost {
     std::vector<int32_t> range_end_of_window;   // [n_windows] end of the range a window belongs to
     int ring = 1, slot16 = 0;             // half-window schedule: slots in the LDS, 16-byte units per slot
     int look = 0;                         // ... sub-windows beyond the epoch's own a row may work ahead in (ring - 1)
-    int sync_stage = 0;                   // ... 1: slots refilled AT the epoch boundary; 2: double-buffered (look = 0)
+    int sync_stage = 0;                   // ... 1 whenever ring > 1 (slots refilled AT the epoch boundary)
     bool single = false;                  // steps count nonzeros (stored: (steps + 1) / 2 slots), see above
     int row_slots = 0;                    // 16-byte units per table row (KP * sizeof(T) / 16)
     int64_t nnz = 0, n_blocks = 0, n_tasks = 0, n_partial_rows = 0, pstride = 0;
@@ -186,7 +180,7 @@ struct TilePlanHost {
 struct TileShape {
     int lpc = 1, waves_per_block = 16, win_rows = 1, target_tasks = 0, row_slots = 1;
     int ring = 1, slot_bytes = 0;
-    int sync_stage = 0;        // ring >= 2: 1 = the HALF-WINDOW schedule above, 2 = DOUBLE-BUFFERED sub-windows (ring == 2)
+    int sync_stage = 0;        // 1 with ring >= 2: the HALF-WINDOW schedule above
     bool single = false;       // steps count nonzeros (not with the work-ahead of sync_stage 1)
     int slots = 0;          // workgroups of this orientation the GPU runs at once (0: unknown); see tile_plan_begin
     int ranges = 0;         // > 0: window ranges (tasks) per block, fixed by the caller (choose_task_ranges);

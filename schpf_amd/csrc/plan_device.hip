@@ -75,7 +75,6 @@ __global__ void fill_i64_kernel(int64_t n, int64_t v, int64_t *__restrict__ out)
 struct Geometry {
     int gpb, gpw, wpb, W, win_rows, lpc, lpc_shift, n_classes, row_slots, packed;
     int ring, slot16, look;
-    int sched;    // 1: the work-ahead schedule (ring > 1 with look > 0): segments come from ring_schedule_kernel
     int single;   // steps count nonzeros (plan.h)
 };
 
@@ -222,7 +221,7 @@ __device__ __forceinline__ void segment_bounds(const Geometry &g, int64_t slot, 
                                                const int32_t *__restrict__ s_minor, const int32_t *__restrict__ start,
                                                int64_t &s, int64_t &e_)
 {
-    if (g.sched) {   // work-ahead schedule: what it gave this lane in epoch w
+    if (g.ring > 1) {   // ring mode: what the schedule gave this lane in epoch w
         const int32_t *st = start + (size_t)slot * ((size_t)g.W + 1);
         s = r0 + st[w];
         e_ = r0 + st[w + 1];
@@ -482,8 +481,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         g.row_slots = P.row_slots;
         g.ring = P.ring; g.slot16 = P.slot16;
         g.look = P.look;
-        const bool ring = P.ring > 1 && P.look > 0;   // the work-ahead schedule; double-buffered sub-windows build like windows
-        g.sched = ring ? 1 : 0;
+        const bool ring = P.ring > 1;
         g.single = P.single ? 1 : 0;
         const int64_t n_slots = P.n_blocks * P.gpb;
         Tmp d_rows((size_t)n_slots * 4);
@@ -541,7 +539,7 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         Tmp d_woff(win_off.size() * 8), d_rank(pass_rank.size() * 4);
         PD_CHECK(hipMemcpyAsync(d_woff.p, win_off.data(), win_off.size() * 8, hipMemcpyHostToDevice, st));
         PD_CHECK(hipMemcpyAsync(d_rank.p, pass_rank.data(), pass_rank.size() * 4, hipMemcpyHostToDevice, st));
-        if (P.ring > 1 && n_steps > 0)
+        if (ring && n_steps > 0)
             hipLaunchKernelGGL(ring_pad_kernel, dim3((unsigned)((n_steps + 255) / 256)), dim3(256), 0, st, g,
                                (int64_t)P.n_blocks * P.wpb, d_woff.as<int64_t>(), d_steps32.as<unsigned>(),
                                static_cast<uint32_t *>(d_entries));
@@ -749,8 +747,7 @@ void balance_windows_device(void *stream, int64_t nnz, const int32_t *d_major, c
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     *d_minor_of = nullptr;
-    if (shape.ring > 1 && shape.sync_stage != 2)
-        throw std::invalid_argument("balanced windows need windows without work-ahead (ring <= 1, or double-buffered)");
+    if (shape.ring > 1) throw std::invalid_argument("balanced windows need whole windows (ring <= 1)");
     const int threads = 256;
     // row lengths -> the blocks the builder will cut (tile_plan_begin depends on the lengths only)
     Tmp d_count((size_t)n_major * 4);

@@ -474,7 +474,6 @@ template <> struct TileEntry<true> {      // {idx0 | idx1 << 16, cnt0 | cnt1 << 
         const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(base) + i);
         return make_uint2(v.x, v.y);
     }
-    static __device__ __forceinline__ void touch(const uint2 &e) { asm volatile("" :: "v"(e.x), "v"(e.y)); }
     static __device__ __forceinline__ unsigned idx(const uint2 &e, int u) { return u ? e.x >> 16 : e.x & 0xFFFFu; }
     static __device__ __forceinline__ float val(const uint2 &e, int u) { return (float)(u ? e.y >> 16 : e.y & 0xFFFFu); }
 };
@@ -484,7 +483,6 @@ template <> struct TileEntry<false> {     // {idx0, val0, idx1, val1}
     {
         return stream_load(reinterpret_cast<const uint4 *>(base) + i);
     }
-    static __device__ __forceinline__ void touch(const uint4 &e) { asm volatile("" :: "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w)); }
     static __device__ __forceinline__ unsigned idx(const uint4 &e, int u) { return u ? e.z : e.x; }
     static __device__ __forceinline__ float val(const uint4 &e, int u) { return __uint_as_float(u ? e.w : e.y); }
 };
@@ -556,30 +554,15 @@ __device__ __forceinline__ void step_row_load(const T *__restrict__ row, int sub
     load_lane<T, NV, LPC>(row, sub, v);
 }
 
-// LDS-DMA that the compiler does not see (double-buffered sub-windows, plan.h): a 16-byte piece per lane, global ->
-// LDS at lds_addr + 16 * lane.  With the builtin, hipcc orders every later ds_read behind the copy (s_waitcnt vmcnt(0)
-// in front of the first LDS read: the copy would be exposed again) and drains it with the entry loads; an asm
-// statement is neither counted nor waited for -- the kernel waits itself (s_waitcnt vmcnt(0) in front of the
-// sub-window's barrier).  Vector-memory loads return in order, so the compiler's own counted waits on the entry
-// loads stay sufficient: they can only wait for more than they name.  M0 is saved and restored (compiler-reserved).
-__device__ __forceinline__ void hidden_dma16(const void *gsrc, unsigned lds_addr)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-}
-
 // the minor row an entry points at: LDS position in 16-byte units
 template <typename T> __device__ __forceinline__ const T *lds_row(const unsigned char *lds, unsigned off16)
 {
     return reinterpret_cast<const T *>(lds + (off16 << 4));
 }
 
-// BAL: 1 = balanced windows (plan.h), 2 = balanced AND double-buffered sub-windows (plan.h, round 5: the schedule is a
-// compile-time fact so that the compiler's wait-count bookkeeping of one schedule does not leak into the other where
-// their paths join) -- instantiations of their own (1024-thread workgroups only), so that the row-list
+// BAL: balanced windows (plan.h) -- an instantiation of its own (1024-thread workgroups only), so that the row-list
 // staging costs the kernels of index-cut windows neither registers nor instructions
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, int BAL = 0>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
 __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, const int task)
 {
     typedef TileEntry<PACK> EF;
@@ -639,17 +622,8 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     // live through the step loop), and handed to the copying lanes by ds_bpermute -- no load in front of the copies
     constexpr int ROW_SLOTS = KP * (int)sizeof(T) / 16;
     constexpr int RPI = 64 / ROW_SLOTS;     // whole rows per copy instruction
-    // double-buffered sub-windows (plan.h): the copies of sub-window w + 1 run under the steps of w, hidden from the compiler
-    constexpr bool db = BAL == 2;
-    constexpr bool BALANCED = BAL != 0;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds_raw;
-    auto copy16 = [&](const unsigned char *gsrc, unsigned char *dst) {   // dst: wave-uniform, the lane's piece lands at dst + 16 * lane
-        if (db) hidden_dma16(gsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(dst - lds_raw))));
-        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                              (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    };
-    const int rpw = BALANCED ? (a.win_rows + a.wpb - 1) / a.wpb : 0;
-    const bool rows_ahead = BALANCED && rpw <= 128;
+    const int rpw = BAL ? (a.win_rows + a.wpb - 1) / a.wpb : 0;
+    const bool rows_ahead = BAL && rpw <= 128;
     int rows_lo = -1, rows_hi = -1;
     auto fetch_rows = [&](int sw) {
         if (!rows_ahead) return;
@@ -660,11 +634,11 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         rows_lo = (lane < rpw && l < nr) ? list[l] : -1;
         rows_hi = (lane + 64 < rpw && l + 64 < nr) ? list[l + 64] : -1;
     };
-    if (BALANCED && MODE != MODE_RANDOM) fetch_rows(w0);
+    if (BAL && MODE != MODE_RANDOM) fetch_rows(w0);
     auto stage = [&](int sw, int slot) {
         const int r0 = sw * a.win_rows;
         const int nr = min(a.win_rows, a.n_minor - r0);
-        if (BALANCED && rows_ahead) {
+        if (BAL && rows_ahead) {
             // a wave instruction copies RPI whole rows (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS
             // side of the DMA is base + 16 * lane, so rows land back to back)
             const int rr = lane / ROW_SLOTS, q = lane - rr * ROW_SLOTS;
@@ -679,11 +653,13 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                     row = src < 64 ? row : hi;
                 }
                 if (rr < RPI && src < rpw && row >= 0)
-                    copy16(tab + ((size_t)row * ROW_SLOTS + q) * 16, dst + (size_t)u * RPI * ROW_SLOTS * 16);
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(tab + ((size_t)row * ROW_SLOTS + q) * 16),
+                        (__attribute__((address_space(3))) void *)(dst + (size_t)u * RPI * ROW_SLOTS * 16), 16, 0, 0);
             }
             return;
         }
-        if constexpr (BALANCED) {
+        if constexpr (BAL) {
             // (very narrow rows: more than 128 rows per wave) the row numbers of a batch of copy instructions are
             // fetched in the staging itself, then the copies go out.  A wave instruction copies RPI whole rows
             // (lane -> row lane / ROW_SLOTS, 16-byte piece lane % ROW_SLOTS; the LDS side of the DMA is base + 16 * lane,
@@ -708,7 +684,9 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 for (int u = 0; u < BATCH; ++u) {
                     const int i = i0 + u * a.wpb;
                     if (i < n_inst && row[u] >= 0)
-                        copy16(tab + ((size_t)row[u] * ROW_SLOTS + q) * 16, dst + (size_t)i * RPI * ROW_SLOTS * 16);
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(tab + ((size_t)row[u] * ROW_SLOTS + q) * 16),
+                            (__attribute__((address_space(3))) void *)(dst + (size_t)i * RPI * ROW_SLOTS * 16), 16, 0, 0);
                 }
             }
             return;
@@ -718,40 +696,24 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         const int nbytes = nr * KP * (int)sizeof(T);                  // a multiple of 16
         for (int off = wv * 1024; off < nbytes; off += a.wpb * 1024) {   // scalar loop
             const int o = off + lane * 16;
-            if (o < nbytes) copy16(src + o, dst + off);
+            if (o < nbytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                                 (__attribute__((address_space(3))) void *)(dst + off), 16, 0, 0);
         }
     };
     // Window schedule: the whole LDS is window w, refilled between two barriers.  Half-window
     // schedule (a.ring slots, plan.h): the first epoch fills every slot, a later one only the slot
     // that the last epoch's own sub-window had.
-    // Double-buffered sub-windows: sub-window w + 1 is copied into the other slot under the steps of w; before the
-    // barrier that opens w every wave waits for its own copies (the compiler knows nothing of them)
     const int L = a.ring > 1 ? a.ring : 1;
-    if (db && MODE != MODE_RANDOM) {   // the workgroup's previous task is behind a barrier (the task loops)
-        stage(w0, w0 & 1);
-        if (BALANCED && w0 + 1 < w1) fetch_rows(w0 + 1);
-    }
     for (int w = w0; w < w1; ++w) {
-        if (MODE != MODE_RANDOM && db) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // ... which also completed the entry ring primed for this sub-window: say so to the compiler (a use of the
-            // registers makes it wait here, for nothing, instead of in front of the first steps -- where its counted wait
-            // would stand behind the copies issued below)
-#pragma unroll
-            for (int i = 0; i < RING; ++i) EF::touch(ring[i]);
-            __syncthreads();                       // sub-window w has landed, w - 1 is fully consumed
-            if (w + 1 < w1 && (SCHPF_ABLATE != 3)) {
-                stage(w + 1, (w + 1) & 1);
-                if (BALANCED && w + 2 < w1) fetch_rows(w + 2);
-            }
-        } else if (MODE != MODE_RANDOM) {
+        if (MODE != MODE_RANDOM) {
             __syncthreads();                       // previous window fully consumed
             const int sw0 = (L == 1 || w == w0) ? w : w + L - 1;
             const int sw1 = min(w + L, w1);
             if (SCHPF_ABLATE != 3 || w == w0)
             for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
-            if (BALANCED && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
+            if (BAL && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
         }
         // stored step slots of this (wave, window); `single`: steps counts nonzeros, an odd count leaves the second
         // half of its last slot unexecuted in the one-nonzero-at-a-time loop (elsewhere that half has count 0)
@@ -839,18 +801,6 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             // body the compiler gave the row registers different homes on different paths and paid for it with
             // 10 v_mov_b32 per step in the float32 kernel (hipcc -S; 16 % of its VALU instructions)
             int p = 0;
-            if (db) {
-                // the first turn of a double-buffered sub-window on its own: here the compiler knows that the ring is
-                // complete (it was primed before the barrier) and waits for nothing until the turn's own refills come
-                // round -- inside the loop below its counted waits would stand in front of the first steps and, because
-                // loads return in order, wait for the copies of the next sub-window that were issued just above
-#define SCHPF_PIPE_STEP(I)                                                                              \
-    ring[I] = EF::load(a.entries, pos + (size_t)(I + RING) * GPW);                                      \
-    if (I < nsl) pipe_step(std::integral_constant<int, I>{});
-                SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
-#undef SCHPF_PIPE_STEP
-                p = RING;
-            }
             for (; p + RING <= nsl; p += RING) {
 #define SCHPF_PIPE_STEP(I)                                                                              \
     if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
@@ -923,10 +873,6 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
     if (2 * (p + I) + 1 < nz) roll_step(std::integral_constant<int, I>{});
             int p = 0;
-            if (db) {   // the first turn on its own: see the paired loop
-                SCHPF_ROLL_GUARDED(0) SCHPF_ROLL_GUARDED(1) SCHPF_ROLL_GUARDED(2) SCHPF_ROLL_GUARDED(3)
-                p = RING;
-            }
             for (; 2 * (p + RING) <= nz; p += RING) {
 #define SCHPF_ROLL_STEP(I)                                                           \
     ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);               \
@@ -1035,7 +981,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         slow_task_row<T, NV, LPC, PACK>(a.entries, (size_t)a.task_wave_off[(size_t)task * a.wpb + wv] + grp, st, w0, w1,
                                         a.win_rows, a.ring, a.slot_bytes / 16, a.single, GPW, a.log_major + (size_t)major * KP,
                                         a.log_minor, sub, a.K, out_row,
-                                        BALANCED ? a.minor_of + (size_t)blk * a.n_virtual : nullptr);
+                                        BAL ? a.minor_of + (size_t)blk * a.n_virtual : nullptr);
         return;
     }
     if (MODE == MODE_PHI) {
@@ -1047,7 +993,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
 }
 
 
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, int BAL = 0>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
 __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int task)
 {
     tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK, BAL>(a, task);
@@ -1055,7 +1001,7 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
 
 // launch slot -> task: longest tasks first (plan.h task_order), so the launch has a short tail
 // a.queue: persistent workgroups, as in tile_sweep_dual_kernel below
-template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, int BAL = 0>
+template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
 __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
     __shared__ int next_slot;
@@ -1086,7 +1032,7 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 // longest-first list is balanced by who is free, not by the dispatcher's round-robin.  queue[1]
 // counts the workgroups that have found the list empty; the last one zeroes both words for the
 // next launch.
-template <typename T, int NV, int LPC, int MAXT, bool PACK, int BAL = 0>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
 __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, TileArgs<T> a1,
                                                               const int *__restrict__ order, int n_slots,
                                                               int *__restrict__ queue)
@@ -1127,7 +1073,7 @@ static inline bool lds_opt_in_pending(std::atomic<uint64_t> &raised)
     return (raised.fetch_or(bit) & bit) == 0;
 }
 
-template <typename T, int NV, int LPC, int MAXT, bool PACK, int BAL = 0>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
 static hipError_t launch_tile_b(const TileArgs<T> &a_in, int mode, int64_t n_tasks, int threads, size_t lds_bytes,
                                 hipStream_t st)
 {
@@ -1164,19 +1110,14 @@ static hipError_t launch_tile_t(const TileArgs<T> &a, int mode, int packed, int6
     if (threads <= 512)
         return packed ? launch_tile_b<T, NV, LPC, 512, true>(a, mode, n_tasks, threads, lds_bytes, st)
                       : launch_tile_b<T, NV, LPC, 512, false>(a, mode, n_tasks, threads, lds_bytes, st);
-    // double-buffered sub-windows come with the balancing (capi.hip falls back to another schedule when it cannot balance)
-    if (a.sync_stage == 2 && !a.minor_of) return hipErrorInvalidValue;
-    if (a.sync_stage == 2 && mode != MODE_RANDOM)
-        return packed ? launch_tile_b<T, NV, LPC, 1024, true, 2>(a, mode, n_tasks, threads, lds_bytes, st)
-                      : launch_tile_b<T, NV, LPC, 1024, false, 2>(a, mode, n_tasks, threads, lds_bytes, st);
     if (a.minor_of && mode != MODE_RANDOM)   // balanced windows: capi.hip builds them for 1024-thread workgroups only
-        return packed ? launch_tile_b<T, NV, LPC, 1024, true, 1>(a, mode, n_tasks, threads, lds_bytes, st)
-                      : launch_tile_b<T, NV, LPC, 1024, false, 1>(a, mode, n_tasks, threads, lds_bytes, st);
+        return packed ? launch_tile_b<T, NV, LPC, 1024, true, true>(a, mode, n_tasks, threads, lds_bytes, st)
+                      : launch_tile_b<T, NV, LPC, 1024, false, true>(a, mode, n_tasks, threads, lds_bytes, st);
     return packed ? launch_tile_b<T, NV, LPC, 1024, true>(a, mode, n_tasks, threads, lds_bytes, st)
                   : launch_tile_b<T, NV, LPC, 1024, false>(a, mode, n_tasks, threads, lds_bytes, st);
 }
 
-template <typename T, int NV, int LPC, int MAXT, bool PACK, int BAL = 0>
+template <typename T, int NV, int LPC, int MAXT, bool PACK, bool BAL = false>
 static hipError_t launch_dual_b(const TileArgs<T> &a0, const TileArgs<T> &a1, const int *order, int64_t n_slots,
                                 int threads, size_t lds_bytes, int *queue, int resident, hipStream_t st)
 {
@@ -1205,14 +1146,9 @@ static hipError_t launch_dual_t(const TileArgs<T> &a0, const TileArgs<T> &a1, co
         return packed ? launch_dual_b<T, NV, LPC, 512, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
                       : launch_dual_b<T, NV, LPC, 512, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     if ((a0.minor_of != nullptr) != (a1.minor_of != nullptr)) return hipErrorInvalidValue;   // both plans balanced, or neither
-    if ((a0.sync_stage == 2) != (a1.sync_stage == 2)) return hipErrorInvalidValue;           // ... and on one schedule
-    if (a0.sync_stage == 2 && !a0.minor_of) return hipErrorInvalidValue;
-    if (a0.sync_stage == 2)
-        return packed ? launch_dual_b<T, NV, LPC, 1024, true, 2>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
-                      : launch_dual_b<T, NV, LPC, 1024, false, 2>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     if (a0.minor_of)
-        return packed ? launch_dual_b<T, NV, LPC, 1024, true, 1>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
-                      : launch_dual_b<T, NV, LPC, 1024, false, 1>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
+        return packed ? launch_dual_b<T, NV, LPC, 1024, true, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
+                      : launch_dual_b<T, NV, LPC, 1024, false, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
     return packed ? launch_dual_b<T, NV, LPC, 1024, true>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st)
                   : launch_dual_b<T, NV, LPC, 1024, false>(a0, a1, order, n_slots, threads, lds_bytes, queue, resident, st);
 }

@@ -169,23 +169,20 @@ def test_tile_plan_roundtrip(lpc, wpb, win_rows, tasks, ring, slot_bytes, coo_or
         assert np.array_equal(owner[oprow], om)
 
 
-@pytest.mark.parametrize("lpc,wpb,win_rows,ring,slot_bytes", [(4, 8, 64, 1, 0), (1, 1, 1000, 1, 0), (2, 4, 0, -2, 8192),
-                                                             (4, 16, 0, -2, 4000), (1, 16, 0, -2, 1024)])
-@pytest.mark.parametrize("single,balanced", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("lpc,wpb,win_rows", [(4, 8, 64), (1, 1, 1000), (4, 16, 9), (2, 4, 37)])
+@pytest.mark.parametrize("balanced", [0, 1])
 @pytest.mark.parametrize("coo_order", ["shuffled", "col-major"])
-def test_double_buffered_and_single_plans_roundtrip(lpc, wpb, win_rows, ring, slot_bytes, single, balanced, coo_order, monkeypatch):
-    """Round 5 schedules (plan.h): double-buffered sub-windows (two slots, no work-ahead: every entry of sub-window w
-    points into slot w % 2, padding included -- the hook checks it) and `single` step counts (an odd count stops in the
-    middle of its last slot).  With or without the balancing, through the kernel's own walk every nonzero must come back
-    exactly once, in a partial row of its major."""
-    monkeypatch.setenv("SCHPF_DEBUG_SYNC_STAGE", "2")
-    monkeypatch.setenv("SCHPF_DEBUG_SINGLE", str(single))
+def test_single_step_counts_roundtrip(lpc, wpb, win_rows, balanced, coo_order, monkeypatch):
+    """`single` step counts (plan.h, round 5): the steps of a (wave, window) count nonzeros, an odd count stops in the
+    middle of its last stored slot.  With or without the balancing, through the kernel's own walk (the hook executes
+    exactly `steps` slot halves) every nonzero must come back exactly once, in a partial row of its major."""
+    monkeypatch.setenv("SCHPF_DEBUG_SINGLE", "1")
     monkeypatch.setenv("SCHPF_DEBUG_BALANCE", str(balanced))
     X = synthetic_counts(257, 1031, 0.04, seed=5)
     perm = {"shuffled": np.random.RandomState(0).permutation(X.nnz), "col-major": np.lexsort((X.row, X.col))}[coo_order]
     row, col, val = X.row[perm], X.col[perm], X.data[perm].astype(np.float32)
     for major, minor, nM, nm in ((row, col, 257, 1031), (col, row, 1031, 257)):
-        om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, 16, ring, slot_bytes)
+        om, on, ov, oprow, otask, pfirst, pcount, st = expand_tile(major, minor, val, nM, nm, lpc, wpb, win_rows, 16)
         n_tasks, n_blocks, n_windows, pstride, slots = st[:5]
         key_in = major.astype(np.int64) * nm + minor
         key_out = om.astype(np.int64) * nm + on

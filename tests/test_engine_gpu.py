@@ -25,20 +25,16 @@ def plan_kind(request, monkeypatch):
     balances sparse, wide problems like the C5 share), and the L2-gather plan (selected by the library
     from SCHPF_PLAN at upload time).  A test that belongs to some of them narrows the list with
     `only_plans(...)` -- no ids that can only skip -- and the tests of the iteration itself add "balanced"
-    and "db" (double-buffered sub-windows, SCHPF_DB=1: the next sub-window copied under the steps; `every_plan`)."""
-    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param in ("half", "balanced", "db") else request.param)
+    (`every_plan`)."""
+    monkeypatch.setenv("SCHPF_PLAN", "tile" if request.param in ("half", "balanced") else request.param)
     monkeypatch.delenv("SCHPF_HALF", raising=False)
     monkeypatch.delenv("SCHPF_BALANCE", raising=False)
-    monkeypatch.delenv("SCHPF_DB", raising=False)
     if request.param == "half":
         monkeypatch.setenv("SCHPF_HALF", "2")
     monkeypatch.delenv("SCHPF_WPB", raising=False)
     if request.param == "balanced":
         monkeypatch.setenv("SCHPF_BALANCE", "1")
         monkeypatch.setenv("SCHPF_WPB", "16")     # the balanced kernels are the 1024-thread ones
-    if request.param == "db":                     # double-buffered sub-windows (round 5; balanced, 1024 threads)
-        monkeypatch.setenv("SCHPF_DB", "1")
-        monkeypatch.setenv("SCHPF_WPB", "16")
     return request.param
 
 
@@ -46,7 +42,7 @@ def only_plans(*kinds):
     return pytest.mark.parametrize("plan_kind", list(kinds), indirect=True)
 
 
-every_plan = only_plans("tile", "half", "gather", "balanced", "db")
+every_plan = only_plans("tile", "half", "gather", "balanced")
 
 
 @pytest.fixture(scope="module")
@@ -395,7 +391,7 @@ def test_xcd_launch_order_changes_nothing_but_the_order(amd, oracle, plan_kind, 
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
-@only_plans("tile", "half", "balanced", "db")
+@only_plans("tile", "half", "balanced")
 def test_persistent_dual_launch_equals_one_workgroup_per_task_bitwise(amd, oracle, plan_kind, monkeypatch):
     """The dual sweep launch as persistent workgroups that draw tasks from a device counter (default)
     against one workgroup per task (SCHPF_PERSISTENT=0), with more tasks than the device holds at once so
@@ -477,7 +473,7 @@ def test_real_valued_data_and_stored_zeros_match_oracle(amd, oracle, dtype, plan
         assert_allclose(loss, want, rtol=1e-5 if f32 else 5e-7)
 
 
-@only_plans("tile", "balanced", "db")
+@only_plans("tile", "balanced")
 @pytest.mark.parametrize("device_plan", ["1", "0"])
 def test_duplicate_entries_match_oracle(amd, oracle, plan_kind, device_plan, monkeypatch):
     """A COO may hold an entry twice; the reference treats every stored entry as a nonzero of its own
@@ -971,7 +967,7 @@ def test_skewed_expression_matrix_matches_oracle(amd, oracle, plan_kind):
             assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-10)
 
 
-@only_plans("tile", "half", "balanced", "db")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, monkeypatch):
     """One launch for both orientations (tile_sweep_dual_kernel) runs the same tasks with the same
@@ -992,7 +988,7 @@ def test_dual_launch_equals_two_launches_bitwise(amd, oracle, dtype, plan_kind, 
             assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
 
 
-@only_plans("tile", "half", "balanced", "db")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype,K", [(np.float64, 20), (np.float32, 20), (np.float64, 50)])
 def test_loss_is_the_same_on_either_plan(amd, oracle, plan_kind, monkeypatch, dtype, K):
     """The loss pass sweeps ONE tile plan -- the cell-side one, or the gene-side one when the cell side has too few
@@ -1018,7 +1014,7 @@ def test_loss_is_the_same_on_either_plan(amd, oracle, plan_kind, monkeypatch, dt
     assert_allclose(got[0], want, rtol=1e-5 if f32 else 1e-10)
 
 
-@only_plans("tile", "half", "balanced", "db")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
 @pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True),
                                          (np.float64, 50, False)])
@@ -1197,7 +1193,7 @@ def test_a_new_communicator_drops_the_captured_stretch(amd, oracle, plan_kind):
             eng.steps_sharded(4)                                              # no communicator, no stale graph
 
 
-@only_plans("tile", "half", "balanced", "db")
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("graph", ["0", "1"])
 def test_sharded_stretches_with_mode_switches_match_oracle(amd, oracle, plan_kind, dtype, graph, monkeypatch):
