@@ -536,24 +536,6 @@ struct LlhAccumulator {
     __device__ __forceinline__ double total() const { return sum - rsum; }
 };
 
-// Ablation switches of development builds (tools/devbuild.sh, DEVFLAGS=-DSCHPF_ABLATE=n; timing
-// experiments only, the results are wrong):  1 = no LDS row reads in the step loop (the registers keep the
-// prologue's rows, made opaque so that nothing is hoisted), 2 = no accumulation FMAs, 3 = no window
-// staging, 4 = no entry stream (the ring keeps its first entries), 5 = no dot product (weights = counts).
-#ifndef SCHPF_ABLATE
-#define SCHPF_ABLATE 0
-#endif
-template <typename T, int NV, int LPC>
-__device__ __forceinline__ void step_row_load(const T *__restrict__ row, int sub, T (&v)[NV * Vec16<T>::N])
-{
-    if (SCHPF_ABLATE == 1) {
-#pragma unroll
-        for (int k = 0; k < NV * Vec16<T>::N; ++k) asm volatile("" : "+v"(v[k]));
-        return;
-    }
-    load_lane<T, NV, LPC>(row, sub, v);
-}
-
 // the minor row an entry points at: LDS position in 16-byte units
 template <typename T> __device__ __forceinline__ const T *lds_row(const unsigned char *lds, unsigned off16)
 {
@@ -710,7 +692,6 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             __syncthreads();                       // previous window fully consumed
             const int sw0 = (L == 1 || w == w0) ? w : w + L - 1;
             const int sw1 = min(w + L, w1);
-            if (SCHPF_ABLATE != 3 || w == w0)
             for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
             if (BAL && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps
@@ -750,15 +731,14 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                     // (inf or NaN) -- detected once, after the task, and the group is then redone by
                     // the cold path.  A small but normal s is exact enough: its largest term is a
                     // normal number.
-                    const T s0 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bA);
-                    const T s1 = SCHPF_ABLATE == 5 ? T(1) : group_dot<T, KL, LPC>(tm, bB);
+                    const T s0 = group_dot<T, KL, LPC>(tm, bA);
+                    const T s1 = group_dot<T, KL, LPC>(tm, bB);
                     if (MODE == MODE_PHI) {
                         const T q0 = fast_div(x0, s0);
                         const T q1 = fast_div(x1, s1);
-                        if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q0, bA[0], acc[0]); acc[1] = fma_t(q0, bA[KL - 1], acc[1]); } else
 #pragma unroll
                         for (int k = 0; k < KL; ++k) acc[k] = fma_t(q0, bA[k], acc[k]);
-                        step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
+                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
                         // nothing moves across: row A' must be requested BEFORE nonzero B is accumulated.  The
                         // scheduling barrier holds the machine scheduler; in the straight-line float32 turn the
                         // optimiser had already hoisted B's accumulation above the loads (hipcc -S: the next dot
@@ -775,10 +755,9 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        if (SCHPF_ABLATE == 2) { acc[0] = fma_t(q1, bB[0], acc[0]); acc[1] = fma_t(q1, bB[KL - 1], acc[1]); } else
 #pragma unroll
                         for (int k = 0; k < KL; ++k) acc[k] = fma_t(q1, bB[k], acc[k]);
-                        step_row_load<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
+                        load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
                     } else {
                         load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n0), sub, bA);
                         load_lane<T, NV, LPC>(lds_row<T>(lds_raw, n1), sub, bB);
@@ -803,7 +782,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
             int p = 0;
             for (; p + RING <= nsl; p += RING) {
 #define SCHPF_PIPE_STEP(I)                                                                              \
-    if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
+    ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);                                  \
     pipe_step(std::integral_constant<int, I>{});
                 SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
 #undef SCHPF_PIPE_STEP
@@ -813,7 +792,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                 // the window's last step that is the next window's entry or padding: its indices are in range, the
                 // rows read with them are never used
 #define SCHPF_PIPE_STEP(I)                                                                              \
-    if (SCHPF_ABLATE != 4) ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);           \
+    ring[I] = EF::load(a.entries, pos + (size_t)(p + I + RING) * GPW);                                  \
     if (p + I < nsl) pipe_step(std::integral_constant<int, I>{});
                 SCHPF_PIPE_STEP(0) SCHPF_PIPE_STEP(1) SCHPF_PIPE_STEP(2) SCHPF_PIPE_STEP(3)
 #undef SCHPF_PIPE_STEP
@@ -1039,9 +1018,6 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, T
 {
     __shared__ int next_slot;
     int slot = blockIdx.x;
-#if SCHPF_ABLATE == 9
-    if (threadIdx.x == 0 && blockIdx.x == 0) a0.wave_out[gridDim.x] = (double)wall_clock64();   // launch start
-#endif
     for (;;) {
         const int code = order[slot];
         if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>(a0, code);
@@ -1053,9 +1029,6 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, T
         slot = next_slot;
         if (slot >= n_slots) break;
     }
-#if SCHPF_ABLATE == 9   /* tail study: when each persistent workgroup ran dry (wave_out is unused by MODE_PHI) */
-    if (threadIdx.x == 0) a0.wave_out[blockIdx.x] = (double)wall_clock64();
-#endif
     if (threadIdx.x == 0 && atomicAdd(&queue[1], 1) == (int)gridDim.x - 1) {
         queue[0] = 0;
         queue[1] = 0;

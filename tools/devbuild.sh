@@ -1,7 +1,6 @@
 #!/bin/bash
 # Development build: only the K = 20 / K = 50 sweep instantiations (seconds instead of minutes per file).
 #   tools/devbuild.sh [tag]      -> schpf_amd/libschpf_hip_dev[_tag].so  (use with SCHPF_LIB_PATH=...)
-#   DEVFLAGS="-DSCHPF_ABLATE=1" tools/devbuild.sh a1     timing ablations of the step loop (sweep_impl.h)
 set -e
 tag=${1:+_$1}
 cd "$(dirname "$0")/../schpf_amd/csrc"
