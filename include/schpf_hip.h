@@ -258,11 +258,6 @@ int schpf_debug_tile_expand(int64_t nnz, const int32_t *major, const int32_t *mi
                             int32_t *out_minor, float *out_val, int32_t *out_prow, int32_t *out_task,
                             int32_t *out_pfirst, int32_t *out_pcount, int64_t stats[8]);
 
-/* Measurement hook: the first n doubles of the engine's per-wave output buffer (the loss sweep's partial
- * sums; development builds with -DSCHPF_ABLATE=9 leave each persistent workgroup's finishing time there,
- * tools/tail_study.py). */
-int schpf_debug_read_wave_out(schpf_ctx *ctx, double *out, int64_t n);
-
 #pragma GCC visibility pop
 
 #ifdef __cplusplus

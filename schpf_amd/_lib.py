@@ -63,7 +63,6 @@ SIGNATURES = {
     "schpf_profile_read": [_vp, _dblp, _i64p],
     "schpf_plan_info": [_vp, _i64p],
     "schpf_upload_info": [_vp, _i64p],
-    "schpf_debug_read_wave_out": [_vp, _vp, _i64],
     "schpf_coo_marginals": [_i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp],
     "schpf_debug_plan_expand": [_i64, _vp, _vp, _vp, _int, _int, _int, _int, _int,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _i64p],

@@ -255,7 +255,6 @@ struct schpf_ctx {
     }
     virtual void exchange(void **p, int64_t *count) = 0;
     virtual void loss_terms(double *llh, double *gl, int64_t *nnz) = 0;
-    virtual void read_wave_out(double *out, int64_t n) = 0;
     virtual void plan_info(int64_t info[16]) = 0;
     virtual void upload_info(int64_t info[4]) = 0;
     double a = 0.3, c = 0.3, bp = 1.0, dp = 1.0;
@@ -920,10 +919,11 @@ template <typename T> struct Engine final : schpf_ctx {
         //    half of C3's cells 4 / 8: the cell side +1..4 % with it; 1/8: +2 %), >= 4 in the two-launch
         //    iteration of a row shard (1/8 of C3: sweeps 2 x 70 -> 2 x 63 us).
         // SCHPF_HALF = 0 / slots overrides.
-        // one-nonzero-at-a-time kernels (sweep_impl.h ROLL: float64 rows wider than 96 bytes per lane) count their
-        // steps in nonzeros wherever rows do not work ahead
-        const bool roll_kernel = sizeof(T) == 8 && (size_t)KL * sizeof(T) > 96 && wpb >= 12;
-        sh.single = roll_kernel && env_int("SCHPF_SINGLE", 1) != 0;
+        // one-nonzero-at-a-time kernels (sweep_impl.h: rows wider than 96 bytes per lane in the 1024-thread workgroup --
+        // the rolling loop in float64, the plain loop in float32) count their steps in nonzeros wherever rows do not
+        // work ahead
+        const bool one_at_a_time = (size_t)KL * sizeof(T) > 96 && wpb >= 12;
+        sh.single = one_at_a_time && env_int("SCHPF_SINGLE", 1) != 0;
         {
             const int half_env = env_int("SCHPF_HALF", -1);
             int n_slots = half_env >= 2 ? half_env : 0;
@@ -1588,13 +1588,6 @@ template <typename T> struct Engine final : schpf_ctx {
         return (tcell.n_tasks < 2 * resident && tgene.n_tasks > tcell.n_tasks) ? 1 : 0;
     }
 
-    void read_wave_out(double *out, int64_t n) override
-    {
-        if (n < 0 || (size_t)n * sizeof(double) > wave_out.bytes) throw std::invalid_argument("n out of range");
-        HIPCHK(hipMemcpyAsync(out, wave_out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-    }
-
     void upload_info(int64_t info[4]) override
     {
         info[0] = nnz; info[1] = n_rounded; info[2] = n_zero;
@@ -1935,11 +1928,6 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
 }
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]) { CTX_CALL(ctx->plan_info(info)); }
 int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]) { CTX_CALL(ctx->upload_info(info)); }
-int schpf_debug_read_wave_out(schpf_ctx *ctx, double *out, int64_t n)
-{
-    if (!out) return fail("out is NULL");
-    CTX_CALL(ctx->read_wave_out(out, n));
-}
 
 int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind,
                         int ncells, int ngenes, double *row_sums, double *col_sums)

@@ -910,9 +910,11 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
                     } else {
                         // wide rows (two of them do not fit the registers): one nonzero at a time.  As in the
                         // pipelined loop there is no test of the normaliser: an underflowed s poisons the
-                        // group's accumulators (inf / NaN), which is detected once after the task
+                        // group's accumulators (inf / NaN), which is detected once after the task.  With `single`
+                        // step counts an odd count does not execute the second half of its last slot
+                        const int halves = a.single ? min(2, steps - 2 * (p + i)) : 2;
 #pragma unroll 1
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < halves; ++u) {
                             T b[KL];
                             load_lane<T, NV, LPC>(lds_row<T>(lds_raw, u ? i1 : i0), sub, b);
                             const T x = (T)(u ? xf1 : xf0);
