@@ -116,6 +116,11 @@ struct TileDev {
     schpf::TilePlanHost host;   // entries/steps cleared after upload; order/mptr kept
     DevBuf entries, steps, block_rows, task_block, task_w0, task_w1, task_wave_off, pfirst, pcount, partials;
     DevBuf task_order;          // tasks by decreasing work: the slot list of a persistent single-side launch
+    // The loss pass (MODE_LLH) writes no partial rows, so its tasks may be cut finer than the iteration's: sub-ranges of
+    // the tasks' window ranges, enough of them for a few rounds of the device (Engine::loss_tasks)
+    DevBuf llh_block, llh_w0, llh_w1, llh_stage_end, llh_wave_off, llh_order;
+    int64_t n_llh_tasks = 0;
+    double llh_model = 0.0;     // modelled length of the loss pass on this plan, in step units (0: unknown)
     DevBuf minor_of;            // balanced windows (plan.h): [n_blocks * n_virtual] table row staged at a window position, or empty
     int n_virtual = 0;
     DevBuf order_dev;           // device-built plans: (major, minor)-sorted position -> caller's COO position
@@ -273,6 +278,9 @@ template <typename T> struct Engine final : schpf_ctx {
     DevBuf s_theta, s_beta, s_beta_next;            // double[K]
     DevBuf colpart_cell, colpart_gene;              // double[UPD_BLOCKS * K]
     DevBuf wave_out, scalars;                       // llh per wave; scalars[0]=llh sum
+    // the loss pass's two results land in pinned host memory that the device writes directly: the reduction kernels
+    // store there, the host reads after the stream has drained -- no copy of 24 bytes out of pageable memory per check
+    double *loss_host = nullptr;
     PlanDev cell, gene;                             // gather plans: major = cell / major = gene
     TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
     DevBuf dual_order;                              // merged launch order of both plans' tasks (or empty)
@@ -373,6 +381,10 @@ template <typename T> struct Engine final : schpf_ctx {
         colpart_cell.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
         colpart_gene.alloc((size_t)UPD_BLOCKS * K * sizeof(double));
         scalars.alloc(8 * sizeof(double), true, stream);
+        if (hipHostMalloc((void **)&loss_host, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            loss_host = nullptr;            // falls back to the copy out of `scalars`
+        } else std::memset(loss_host, 0, 8 * sizeof(double));
     }
     void hypers_changed() override { drop_graph(); }
     // the engine holds no count matrix any more: plans, row copy and captured graphs released; step / loss calls
@@ -506,6 +518,7 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         drop_graph();
         (void)hipStreamSynchronize(stream);
+        if (loss_host) (void)hipHostFree(loss_host);
         if (own_stream) (void)hipStreamDestroy(stream);
     }
 
@@ -601,6 +614,105 @@ template <typename T> struct Engine final : schpf_ctx {
         schpf::BigVec<uint32_t>().swap(h.entries);
     }
 
+    // Tasks of the loss pass.  The iteration's task ranges are chosen for the merged launch of both orientations and for
+    // few partial rows (C3 f64: ONE range per cell block = 196 tasks on 256 compute units -- a loss pass over them ran
+    // 0.42 ms where half a dual launch is 0.32); the loss pass keeps no partial rows, so every task's window range may be
+    // cut into `parts` sub-ranges (never below two windows / four sub-windows per sub-task: a first window costs a staging
+    // and the major rows).  `parts` is the count in 1..8 with the shortest modelled pass: the sub-tasks, longest first,
+    // on the resident workgroups (list schedule), a sub-task = its barrier-limited steps + two per window + a fixed cost.
+    // What decides is the last round: 784 equal tasks on 256 workgroups take four rounds, not 3.06 (measured: 0.46 ms
+    // against 0.41 for the gene-side plan's 640).  The modelled time also picks the plan (loss_side).  Needs the host
+    // copies of steps / task_wave_off.
+    void loss_tasks(TileDev &td)
+    {
+        auto &h = td.host;
+        td.n_llh_tasks = 0;
+        td.llh_model = 0.0;
+        for (DevBuf *b : {&td.llh_block, &td.llh_w0, &td.llh_w1, &td.llh_stage_end, &td.llh_wave_off, &td.llh_order}) b->release();
+        if (h.n_tasks <= 0 || h.steps.empty() || h.task_wave_off.empty()) return;
+        const int wpb = h.wpb, W = h.n_windows;
+        const size_t lds = h.ring > 1 ? (size_t)h.ring * h.slot16 * 16 : (size_t)h.win_rows * KP * sizeof(T);
+        const int resident = n_cu() * per_cu(lds);
+        const int min_windows = h.ring > 1 ? 4 : 2;   // sub-windows of the half-window schedule are half as long
+        const double task_cost = (double)env_int("SCHPF_LOSS_TASK_STEPS", 8);
+        // barrier-limited steps (+ 2) of every (block, window)
+        std::vector<int32_t> wwork((size_t)h.n_blocks * W);
+        for (int64_t b = 0; b < h.n_blocks; ++b)
+            for (int w = 0; w < W; ++w) {
+                int mx = 0;
+                for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, h.steps[((size_t)b * wpb + v) * W + w]);
+                wwork[(size_t)b * W + w] = (int32_t)schpf::tile_stored_steps(h, mx) + 2;
+            }
+        auto cut_points = [&](int64_t t, int parts, std::vector<int> &cuts) {   // sub-range starts of task t, + its end
+            const int a0 = h.task_w0[(size_t)t], a1 = h.task_w1[(size_t)t];
+            const int n = std::max(1, std::min(parts, (a1 - a0) / min_windows));
+            cuts.clear();
+            for (int p = 0; p <= n; ++p) cuts.push_back(a0 + (int)((int64_t)(a1 - a0) * p / n));
+        };
+        std::vector<int> cuts;
+        std::vector<double> dur, load;
+        auto model = [&](int parts) {
+            dur.clear();
+            for (int64_t t = 0; t < h.n_tasks; ++t) {
+                cut_points(t, parts, cuts);
+                const int32_t *ww = wwork.data() + (size_t)h.task_block[(size_t)t] * W;
+                for (size_t p = 0; p + 1 < cuts.size(); ++p) {
+                    double d = task_cost;
+                    for (int w = cuts[p]; w < cuts[p + 1]; ++w) d += ww[w];
+                    dur.push_back(d);
+                }
+            }
+            std::sort(dur.begin(), dur.end(), std::greater<double>());
+            load.assign((size_t)resident, 0.0);
+            std::make_heap(load.begin(), load.end(), std::greater<double>());
+            for (double d : dur) {
+                std::pop_heap(load.begin(), load.end(), std::greater<double>());
+                load.back() += d;
+                std::push_heap(load.begin(), load.end(), std::greater<double>());
+            }
+            return *std::max_element(load.begin(), load.end());
+        };
+        int best_parts = 1;
+        double best = model(1);
+        if (env_int("SCHPF_LOSS_SPLIT", 1))
+            for (int parts = 2; parts <= 8; ++parts) {
+                const double m = model(parts);
+                if (m < 0.97 * best) { best = m; best_parts = parts; }   // a cut has to pay for itself
+            }
+        td.llh_model = best;
+        if (env_int("SCHPF_VERBOSE", 0))
+            fprintf(stderr, "[schpf_hip]   loss pass on the %d x %d plan: %d sub-range(s) per task, modelled %.0f step units (uncut %.0f)\n",
+                    h.n_major, h.n_minor, best_parts, best, model(1));
+        if (best_parts <= 1) return;
+        std::vector<int32_t> blk, w0s, w1s, ends, order;
+        std::vector<int64_t> woff;
+        std::vector<double> work;
+        for (int64_t t = 0; t < h.n_tasks; ++t) {
+            const int b = h.task_block[(size_t)t], a1 = h.task_w1[(size_t)t];
+            cut_points(t, best_parts, cuts);
+            std::vector<int64_t> off((size_t)wpb);
+            for (int v = 0; v < wpb; ++v) off[(size_t)v] = h.task_wave_off[(size_t)t * wpb + v];
+            for (size_t p = 0; p + 1 < cuts.size(); ++p) {
+                blk.push_back(b); w0s.push_back(cuts[p]); w1s.push_back(cuts[p + 1]); ends.push_back(a1);
+                for (int v = 0; v < wpb; ++v) woff.push_back(off[(size_t)v]);
+                double wk = 0.0;
+                for (int w = cuts[p]; w < cuts[p + 1]; ++w) {
+                    for (int v = 0; v < wpb; ++v)
+                        off[(size_t)v] += schpf::tile_stored_steps(h, h.steps[((size_t)b * wpb + v) * W + w]) * h.gpw;
+                    wk += wwork[(size_t)b * W + w];
+                }
+                work.push_back(wk);
+            }
+        }
+        order.resize(blk.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return work[(size_t)x] > work[(size_t)y]; });
+        td.n_llh_tasks = (int64_t)blk.size();
+        upload(td.llh_block, blk, stream); upload(td.llh_w0, w0s, stream); upload(td.llh_w1, w1s, stream);
+        upload(td.llh_stage_end, ends, stream); upload(td.llh_wave_off, woff, stream); upload(td.llh_order, order, stream);
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+
     // the small arrays of a tile plan (its entries and steps are on the device already)
     void finish_tile(TileDev &td)
     {
@@ -610,7 +722,8 @@ template <typename T> struct Engine final : schpf_ctx {
         td.threads = 64 * wpb;
         td.lds_bytes = h.ring > 1 ? (size_t)h.ring * h.slot16 * 16 : (size_t)h.win_rows * KP * sizeof(T);
         td.packed = h.packed;
-        td.n_wave_out = h.n_tasks * wpb;
+        loss_tasks(td);
+        td.n_wave_out = std::max<int64_t>(h.n_tasks, td.n_llh_tasks) * wpb;
         upload(td.block_rows, h.block_rows, stream);
         upload(td.task_block, h.task_block, stream);
         upload(td.task_w0, h.task_w0, stream);
@@ -1326,15 +1439,22 @@ template <typename T> struct Engine final : schpf_ctx {
             TileDev &td = cellside ? tcell : tgene;
             auto a = tile_args(td, tmaj, tmin, lmaj, lmin, cellside ? G : N);
             a.seed = seed; a.major_is_cell = cellside ? 1 : 0;
+            int64_t n_tasks = td.n_tasks;
+            const bool cut = mode == schpf::MODE_LLH && td.n_llh_tasks > 0;   // the loss pass's finer tasks (loss_tasks)
+            if (cut) {
+                a.task_block = td.llh_block.as<int>(); a.task_w0 = td.llh_w0.as<int>(); a.task_w1 = td.llh_w1.as<int>();
+                a.task_stage_end = td.llh_stage_end.as<int>(); a.task_wave_off = td.llh_wave_off.as<int64_t>();
+                n_tasks = td.n_llh_tasks;
+            }
             if (mode != schpf::MODE_RANDOM && env_int("SCHPF_PERSISTENT", 1)) {   // see step_local
                 a.queue = dual_queue.as<int>();
                 a.resident = n_cu() * per_cu(td.lds_bytes);
-                a.task_order = td.task_order.as<int>();
-            }
+                a.task_order = cut ? td.llh_order.as<int>() : td.task_order.as<int>();
+            } else if (cut) a.task_order = td.llh_order.as<int>();
             // the loss pass keeps a 1 KiB logarithm table behind the window (sweep_impl.h LlhAccumulator)
             a.llh_tab_off = (int)((td.lds_bytes + 15) & ~(size_t)15);
             const size_t lds = mode == schpf::MODE_LLH ? (size_t)a.llh_tab_off + 1024 : td.lds_bytes;
-            HIPCHK(schpf::launch_tile_sweep<T>(a, NV, LPC, mode, td.packed ? 1 : 0, td.n_tasks, td.threads, lds, stream));
+            HIPCHK(schpf::launch_tile_sweep<T>(a, NV, LPC, mode, td.packed ? 1 : 0, n_tasks, td.threads, lds, stream));
         } else {
             PlanDev &pd = cellside ? cell : gene;
             auto a = sweep_args(pd, tmaj, tmin, lmaj, lmin);
@@ -1557,19 +1677,21 @@ template <typename T> struct Engine final : schpf_ctx {
         ScopedTimer tm(prof, stream, 2);
         const int side = loss_side();
         run_sweep(side, schpf::MODE_LLH);
+        double *res = loss_host ? loss_host : scalars.as<double>();   // pinned host memory is device-addressable as it is
         HIPCHK(schpf::launch_sum_doubles(wave_out.as<double>(),
                                          use_tile ? (side ? tgene.n_wave_out : tcell.n_wave_out) : cell.n_waves,
-                                         scalars.as<double>(), stream));
+                                         res, stream));
         // explicitly stored zeros look like padding to the sweeps (weight 0, which is what they
         // contribute to the shape updates, hpf_numba.py:97-112), but the reference's loss counts
         // them: x log r - r - lgamma(x+1) = -r (hpf_numba.py:43-50)
         if (n_zero > 0)
             HIPCHK(schpf::launch_zero_rate_sum<T>(zero_row.as<int>(), zero_col.as<int>(), n_zero, th_e.as<T>(),
-                                                  be_e.as<T>(), K, KP, scalars.as<double>() + 2, stream));
+                                                  be_e.as<T>(), K, KP, res + 2, stream));
         tm.stop();
         double h[3] = {0.0, 0.0, 0.0};
-        HIPCHK(hipMemcpyAsync(h, scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        if (!loss_host) HIPCHK(hipMemcpyAsync(h, scalars.p, 3 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        if (loss_host) { h[0] = loss_host[0]; h[2] = loss_host[2]; }
         *llh = n_zero > 0 ? h[0] - h[2] : h[0];
         *gl = gammaln_sum;
         *nnz_out = nnz;
@@ -1584,6 +1706,9 @@ template <typename T> struct Engine final : schpf_ctx {
         const int forced = env_int("SCHPF_LOSS_SIDE", -1);
         if (forced == 0 || forced == 1) return use_tile ? forced : 0;
         if (!use_tile || wave_out.bytes < (size_t)tgene.n_wave_out * sizeof(double)) return 0;
+        // the plan with the shorter modelled pass (loss_tasks); the gene side's steps are worth a little more: its windows
+        // are shorter (more stagings per nonzero than the model's two step units per window say)
+        if (tcell.llh_model > 0.0 && tgene.llh_model > 0.0) return tgene.llh_model * 1.05 < tcell.llh_model ? 1 : 0;
         const int64_t resident = (int64_t)n_cu() * per_cu(tcell.lds_bytes);
         return (tcell.n_tasks < 2 * resident && tgene.n_tasks > tcell.n_tasks) ? 1 : 0;
     }

@@ -31,6 +31,9 @@ template <typename T> struct TileArgs {
     const uint16_t *steps;         // [(block * wpb + wave) * n_windows + window]
     const int *block_rows;         // [n_blocks * gpb]
     const int *task_block, *task_w0, *task_w1;
+    // loss pass over SUB-ranges of the tasks (capi.hip loss_tasks): where the sub-task's parent task ends -- entries of
+    // the half-window schedule may point one sub-window beyond the sub-task, and that one is staged too; nullptr: task_w1
+    const int *task_stage_end;
     const int64_t *task_wave_off;  // [task * wpb + wave] first uint4 of the wave's entries in the task
     const int *task_order;         // [launch slot] -> task (longest first); nullptr = identity
     const T *tab_major;            // [n_major, KP]

@@ -557,6 +557,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
     const int blk = a.task_block[task], w0 = a.task_w0[task], w1 = a.task_w1[task];
+    const int stage_end = a.task_stage_end ? a.task_stage_end[task] : w1;   // readable horizon of the half-window schedule
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int grp = lane / LPC, sub = lane % LPC;
     const int gpb = GPW * a.wpb;
@@ -691,7 +692,7 @@ __device__ __forceinline__ void tile_sweep_task_window(const TileArgs<T> &a, con
         if (MODE != MODE_RANDOM) {
             __syncthreads();                       // previous window fully consumed
             const int sw0 = (L == 1 || w == w0) ? w : w + L - 1;
-            const int sw1 = min(w + L, w1);
+            const int sw1 = min(w + L, stage_end);
             for (int sw = sw0; sw < sw1; ++sw) stage(sw, L > 1 ? sw % L : 0);
             __syncthreads();
             if (BAL && w + 1 < w1) fetch_rows(w + 1);   // the next window's rows, under this window's steps

@@ -1015,6 +1015,43 @@ def test_loss_is_the_same_on_either_plan(amd, oracle, plan_kind, monkeypatch, dt
 
 
 @only_plans("tile", "half", "balanced")
+@pytest.mark.parametrize("dtype,K", [(np.float64, 20), (np.float32, 20), (np.float64, 50)])
+@pytest.mark.parametrize("side", ["0", "1"])
+def test_loss_pass_on_finer_tasks_matches_oracle(amd, oracle, plan_kind, monkeypatch, dtype, K, side):
+    """The loss pass keeps no partial rows, so the library cuts the iteration's tasks into sub-ranges of their windows
+    for it (capi.hip loss_tasks; round 5: C3's cell side has ONE task per block, 196 for 256 compute units).  With the
+    iteration's tasks long (one range per block) every task is cut; the loss must agree with the uncut pass
+    (SCHPF_LOSS_SPLIT=0) to summation order and with the oracle (hpf_numba.py:24-51) -- on either plan, with the
+    half-window schedule (whose entries may point one sub-window beyond a sub-task), balanced windows and K = 50's
+    one-nonzero-at-a-time loop, stored zeros included; the iteration itself must not notice."""
+    from scipy.sparse import coo_matrix
+    X = synthetic_counts(6000, 5000, 0.02, seed=29)
+    data = X.data.copy()
+    data[::13] = 0          # explicit zeros
+    X = coo_matrix((data, (X.row, X.col)), shape=X.shape)
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=6)
+    monkeypatch.setenv("SCHPF_LOSS_SIDE", side)
+    monkeypatch.setenv("SCHPF_TASKS", "1")          # one window range per block: tasks as long as they get
+    monkeypatch.setenv("SCHPF_WPB", "16")
+    got, states = [], []
+    for split in ("1", "0"):
+        monkeypatch.setenv("SCHPF_LOSS_SPLIT", split)
+        with load_engine(amd, X, K, dtype, st, 0.3, 0.3, bp, dp) as eng:
+            eng.step()
+            first = eng.mean_negative_pois_llh()
+            eng.step()                               # the sweep after a loss pass sees the iteration's own tasks again
+            got.append((first, eng.mean_negative_pois_llh()))
+            states.append([eng.get_gamma(n) for n in ("theta", "beta")])
+    for (s0, r0), (s1, r1) in zip(states[0], states[1]):
+        assert np.array_equal(s0, s1) and np.array_equal(r0, r1)
+    th, be = states[0]
+    want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, th[0], th[1], be[0], be[1])
+    f32 = np.dtype(dtype) == np.float32
+    assert_allclose(got[0], got[1], rtol=1e-6 if f32 else 1e-12)
+    assert_allclose(got[0][1], want, rtol=1e-5 if f32 else 1e-10)
+
+
+@only_plans("tile", "half", "balanced")
 @pytest.mark.parametrize("coo_order", ["canonical", "shuffled", "col-major"])
 @pytest.mark.parametrize("dtype,K,big", [(np.float64, 20, False), (np.float32, 12, False), (np.float64, 5, True),
                                          (np.float64, 50, False)])
