@@ -318,6 +318,7 @@ template <typename T> struct Engine final : schpf_ctx {
     // (the plans' own order is then the virtual one) and for batch engines, which re-plan every iteration
     bool balance_now = false;
     bool transient = false;             // schpf_hint_transient: the matrix is replaced every iteration, plan the cheapest way
+    bool planning_batch_rows = false;   // inside schpf_upload_rows (gathered batch rows: no loss constants, no loss tasks)
     bool expect_sharded = false;        // schpf_hint_sharded: a rank of a sharded fit (gene-side sums leave for an all-reduce)
     static constexpr int UPD_BLOCKS = 2048;
     static constexpr size_t TABLE_PAD = 256 * 1024;
@@ -630,6 +631,9 @@ template <typename T> struct Engine final : schpf_ctx {
         td.llh_model = 0.0;
         for (DevBuf *b : {&td.llh_block, &td.llh_w0, &td.llh_w1, &td.llh_stage_end, &td.llh_wave_off, &td.llh_order}) b->release();
         if (h.n_tasks <= 0 || h.steps.empty() || h.task_wave_off.empty()) return;
+        // a matrix that is replaced every iteration (minibatch engines: schpf_hint_transient, schpf_upload_rows) is planned the
+        // cheapest way, and batch engines never evaluate the loss themselves
+        if (transient || planning_batch_rows) return;
         const int wpb = h.wpb, W = h.n_windows;
         const size_t lds = h.ring > 1 ? (size_t)h.ring * h.slot16 * 16 : (size_t)h.win_rows * KP * sizeof(T);
         const int resident = n_cu() * per_cu(lds);
@@ -891,7 +895,10 @@ template <typename T> struct Engine final : schpf_ctx {
         use_tile = true;
         const int ranges[2] = {0, 0}, half[2] = {-1, -1};
         // rows in batch order with their columns ascending: sorted by (row, col) already
-        plans_from_device_coo(d_row, d_col, d_val, true, false, src->rows_packed_ok, ranges, half);
+        planning_batch_rows = true;
+        try { plans_from_device_coo(d_row, d_col, d_val, true, false, src->rows_packed_ok, ranges, half); }
+        catch (...) { planning_batch_rows = false; throw; }
+        planning_batch_rows = false;
         wave_out.alloc((size_t)std::max<int64_t>(tcell.n_wave_out, 1) * sizeof(double), true, stream);
         HIPCHK(hipStreamSynchronize(stream));
         n_rounded = 0; n_zero = 0;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, closing measurement on one box: the whole -m gpu suite, the driver-style line, the bench lines of every
 # configuration, then kernel stats + traffic + SQ counters for C3 f64 / f32 and the C5 share (f64).
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r05f; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r05g; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?"
 timeout 2400 python -m pytest tests/ -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err; echo "driver-style rc $?"
@@ -27,6 +27,6 @@ except Exception as e:
     print(sys.argv[1], "unreadable:", e)
 PY
 done
-bash tools/profile_counters.sh r05f c3 f64 20
-bash tools/profile_counters.sh r05f c3 f32 20
-bash tools/profile_counters.sh r05f c5-shard f64 20
+bash tools/profile_counters.sh r05g c3 f64 20
+bash tools/profile_counters.sh r05g c3 f32 20
+bash tools/profile_counters.sh r05g c5-shard f64 20
