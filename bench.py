@@ -628,12 +628,30 @@ def main():
     # with the library's collective one call that keeps the launch queue full (-12 % per iteration against
     # one call per iteration; SCHPF_GRAPH_SHARDED=1 also captures those in a graph)
     use_graph = (not args.eager and not sharded) or (sharded and args.comm == "library")
+    comm_fallback = None
     if sharded and args.comm == "library":
         from schpf_amd.sharded import NativeShard
-        # rank 0's communicator id reaches the other ranks through the process group that is there anyway
-        uid = [DeviceCAVI.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        drv = NativeShard(eng, uid[0], rank, world)
+        # rank 0's communicator id reaches the other ranks through the process group that is there anyway.  The
+        # library's RCCL path with more than one rank has never met hardware: if its communicator cannot be set up on
+        # ANY rank (agreed through the process group), every rank takes the torch.distributed driver of the same
+        # protocol and kernels instead of leaving the run without a line, and the line says so
+        drv, why = None, ""
+        try:
+            uid = [DeviceCAVI.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            drv = NativeShard(eng, uid[0], rank, world)
+        except Exception as e:   # noqa: BLE001 -- whatever it is, the other driver is the answer
+            why = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([1 if drv is not None else 0], dtype=torch.int32,
+                          device=("cuda:%d" % local_rank) if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if drv is not None:
+                eng.comm_destroy()
+            comm_fallback = why or "another rank could not set up the library's communicator"
+            args.comm = "torch"
+            use_graph = False
+            drv = ShardedCAVI(eng, exchange_tensor_of(eng, local_rank))
         step = drv.step
         loss_fn = drv.mean_negative_pois_llh
     elif sharded:
@@ -764,6 +782,9 @@ def main():
                        % (args.warmup, prewarm_evals, args.prewarm_s))
                       if use_graph else "one library call per iteration, eager launches",
             "plan": info,
+            **({"comm_fallback": "the library's RCCL communicator could not be set up (%s): torch.distributed "
+                                 "issues the all-reduce instead, one call per iteration" % comm_fallback}
+               if comm_fallback else {}),
         },
         "roofline": {
             # the nearer roof of the two below; `achieved` / `peak` / `frac` keep SURVEY 8(d)'s definition

@@ -215,6 +215,11 @@ class DeviceCAVI(object):
             raise _lib.SchpfHipError(str(e) + _lib.ipc_hint())
         self.comm_world = int(world)
 
+    def comm_destroy(self):
+        """Leave the communicator (captured stretches that hold its all-reduce are dropped first)."""
+        _lib.check(self._lib.schpf_comm_destroy(self._h))
+        self.comm_world = 0
+
     def steps_sharded(self, n, freeze_genes=False, simultaneous=False):
         """n iterations of the sharded protocol with the all-reduce issued by the library."""
         _lib.check(self._lib.schpf_steps_sharded(self._h, self._flags(freeze_genes, simultaneous), int(n)))
