@@ -548,6 +548,7 @@ def main():
     ap.add_argument("--same-gpu", action="store_true",
                     help="every rank on device 0 (one-GPU boxes: exercises the N > 1 code path of this script with "
                          "--comm torch --backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--fail-library-comm", action="store_true", help=argparse.SUPPRESS)   # tests: exercise the fall-back below
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the wall-clock-to-convergence fits (second half of BASELINE.json's metric)")
     args = ap.parse_args()
@@ -639,6 +640,8 @@ def main():
         try:
             uid = [DeviceCAVI.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
+            if args.fail_library_comm:
+                raise RuntimeError("--fail-library-comm")
             drv = NativeShard(eng, uid[0], rank, world)
         except Exception as e:   # noqa: BLE001 -- whatever it is, the other driver is the answer
             why = "%s: %s" % (type(e).__name__, e)

@@ -164,3 +164,19 @@ def test_bench_line_over_ranks(world):
     assert line["n_gpus"] == world and line["steps"] == 20
     assert np.isfinite(line["value"]) and line["value"] > 0
     assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_falls_back_to_the_torch_collective(world):
+    """`bench.py --gpus N` with the library's communicator failing on every rank (the one thing of that path that has
+    never met hardware with N > 1): all ranks agree through the process group, take the torch.distributed driver of the
+    same protocol, and the line says so instead of the run ending without one."""
+    need_gpus(world)
+    r = _torchrun(world, ["bench.py", "--gpus", str(world), "--config", "c2", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-converge", "--no-traffic", "--fail-library-comm"]
+                  + (["--force-sharded"] if world == 1 else []))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world and "comm_fallback" in line["config"]
+    assert np.isfinite(line["value"]) and line["value"] > 0
+    assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
