@@ -60,8 +60,12 @@ def run(X, K, setting, steps=10):
 
 def main():
     cfg = sys.argv[1]
-    N, G, dens, K = bench.CONFIGS[cfg]
-    X = bench.synthetic_block(N, G, dens, 42)
+    if cfg == "c3-planted":   # the convergence matrix of bench.py: planted Gamma-Poisson factors, skewed rows and columns
+        N, G, K = 100000, 20000, 20
+        X = bench.planted_block(N, G, K, int(N * G * 0.05 * 1.6), 42)
+    else:
+        N, G, dens, K = bench.CONFIGS[cfg]
+        X = bench.synthetic_block(N, G, dens, 42)
     print("matrix", X.shape, X.nnz, flush=True)
     for setting in sys.argv[2:]:
         try:
