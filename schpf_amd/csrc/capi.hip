@@ -983,8 +983,13 @@ template <typename T> struct Engine final : schpf_ctx {
         // cell block -- the uniform model's choice -- doubles the iteration, its heaviest block runs last)
         std::vector<double> share[2];
         const int64_t stride = std::max<int64_t>(1, nnz / 4000000);   // ~4 M samples per orientation: a few ms
-        share[0] = schpf::block_shares(nnz, row, N, (64 / LPC) * 16, stride);
-        share[1] = schpf::block_shares(nnz, col, G, (64 / LPC) * 16, stride);
+        {   // the blocks the plans will cut: rows per block follow the workgroup (a forced SCHPF_WPB=12 has 12 waves)
+            int wpb, lds_kb;
+            pick_workgroup(N, G, wpb, lds_kb);
+            share[0] = schpf::block_shares(nnz, row, N, (64 / LPC) * wpb, stride);
+            pick_workgroup(G, N, wpb, lds_kb);
+            share[1] = schpf::block_shares(nnz, col, G, (64 / LPC) * wpb, stride);
+        }
         const schpf::RangeChoice c = schpf::choose_task_ranges(blocks, half_windows, half_ok, share, (double)nnz, resident,
                                                                1.7e11 / ((double)K * sizeof(T)), 1e-6 * env_int("SCHPF_TASK_US", 3),
                                                                partial_seconds,
