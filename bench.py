@@ -722,12 +722,22 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
 
-    # loss evaluation (every check_freq = 10 iterations in a default fit), outside the timed region
-    fence()
-    t1 = time.perf_counter()
-    loss_end = loss_fn()
-    torch.cuda.synchronize()
-    loss_ms = (time.perf_counter() - t1) * 1e3
+    # loss evaluation (every check_freq = 10 iterations in a default fit), outside the timed region: the median of five,
+    # each right behind an iteration as in a fit (a single sample of a 0.4 ms call read 0.38-0.46 on one build);
+    # loss_after_steps is the first one's value, i.e. the loss after exactly the K timed iterations
+    loss_samples = []
+    loss_end = None
+    for i in range(5):
+        if i:
+            step()
+        fence()
+        t1 = time.perf_counter()
+        val = loss_fn()
+        torch.cuda.synchronize()
+        loss_samples.append((time.perf_counter() - t1) * 1e3)
+        if loss_end is None:
+            loss_end = val
+    loss_ms = float(np.median(loss_samples))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
@@ -825,7 +835,8 @@ def main():
             "gamma_updates_ms": prof["gamma_updates"]["ms"] / max(prof["gamma_updates"]["launches"], 1),
             "iteration_frac_of_hbm_peak": (b_iter / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
         },
-        "loss_eval_ms": loss_ms, "loss_after_warmup": loss_start, "loss_after_steps": loss_end,
+        "loss_eval_ms": loss_ms, "loss_eval_samples_ms": [round(v, 4) for v in loss_samples],
+        "loss_after_warmup": loss_start, "loss_after_steps": loss_end,
         "iterations_per_s_with_loss_every_10": 10.0 / (10 * ms_per_step * 1e-3 + loss_ms * 1e-3),
         "upload_and_plan_s": upload_s,
     }
