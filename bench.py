@@ -16,8 +16,9 @@ row-sharded over the ranks by the product's own nnz-balanced partition
 gene-side sums.
 
 Prints ONE JSON line on rank 0, carrying the driver's contract fields plus
-  roofline     : dominant kernel (the sweep), HIP-event timed, against BOTH roofs -- algorithmic bytes vs
-                 HBM and the essential FMAs vs the vector-FP peak of the dtype; `bound` names the nearer one
+  roofline     : dominant kernel (the sweep), HIP-event timed, against THREE roofs -- algorithmic bytes vs HBM, the
+                 essential FMAs vs the vector-FP peak of the dtype, the LDS bytes vs 256 B/clk/CU -- with the shader
+                 clock measured under the kernel (sclk_mhz); `bound` names the nearest one
   cpu_baseline : the CPU oracle in the reference's execution shape on this box's cores
 """
 import argparse
@@ -39,6 +40,7 @@ CONFIGS = {
     "c3": (100_000, 20_000, 0.05, 20),
     "c5-shard": (125_000, 25_000, 0.02, 50),     # one GPU's 1/8 share of C5 (1M x 25k)
     "c5": (1_000_000, 25_000, 0.02, 50),         # all of C5 on ONE GPU (nnz ~5e8: minutes of host-side generation)
+    "c5-small": (50_000, 25_000, 0.02, 50),      # C5 at 1/20 of its cells, drawn slab by slab like C5 (tests of the per-rank draw)
     "c4-shard": (12_500, 20_000, 0.05, 20),      # one GPU's 1/8 share of C3/C4 (what a rank of --gpus 8 holds)
     "c4-shard2": (50_000, 20_000, 0.05, 20),     # ... of --gpus 2
     "c4-shard4": (25_000, 20_000, 0.05, 20),     # ... of --gpus 4
@@ -47,6 +49,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s 
 # vector (VALU) FMA peaks: FP32 157.3 TFLOP/s (MI355X_MICROARCH.md, chip-level table); FP64 vector is half of it,
 # 78.6 TFLOP/s (public MI355X spec; 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz) -- the sweep has no MFMA work
 VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}
+MAX_CLOCK_MHZ = 2400            # MI355X_MICROARCH.md chip table: the clock the peaks above are quoted at
+LDS_BYTES_PER_CLK_PER_CU = 256  # same guide, LDS section: 64 dwords wide per clock
 
 
 def synthetic_block(ncells, ngenes, density, seed):
@@ -86,50 +90,113 @@ def synthetic_block(ncells, ngenes, density, seed):
     return X
 
 
-def synthetic_slabs(ncells, ngenes, density, seed, slab_rows=25000, threads=None):
-    """Generator A for matrices of several 1e8 draws (all of C5: 5e8): the same recipe drawn slab by
-    slab of `slab_rows` cells, one RandomState(seed + slab) and one thread per slab (NumPy releases the
-    GIL in the draws and in sort), duplicates summed by sorting packed (row, col, count) keys and
-    adding up runs -- coo_matrix.sum_duplicates lexsorts 5e8 entries on one core for minutes.  The
-    result is canonical (row-major, unique) and does not depend on the number of threads."""
-    from concurrent.futures import ThreadPoolExecutor
+SLAB_ROWS = 25000       # cells per slab of the slab generator (one RandomState(seed + slab) each)
+SLAB_CONFIGS = {"c5": SLAB_ROWS, "c5-small": 1250}     # configs drawn slab by slab (40 slabs each): ranks draw their own rows
+
+
+def _slab_draw(ncells, ngenes, density, seed, slab_rows, i):
+    """Slab i of generator A drawn slab by slab: rows [i * slab_rows, ...), canonical (row-major, unique),
+    duplicates summed by sorting packed (row, col, count) keys and adding up runs.  Returns (row, col, count, draws)."""
     bits = max(1, int(ngenes - 1).bit_length())
-    starts = list(range(0, ncells, slab_rows))
+    r0 = i * slab_rows
+    nr = min(slab_rows, ncells - r0)
+    rng = np.random.RandomState(seed + i)
+    n = int(round(nr * ngenes * density))
+    x = rng.negative_binomial(2, 0.5, n)
+    x[x == 0] = 1
+    np.minimum(x, 255, out=x)                      # P(count > 255) is 2^-250; keeps the count in 8 key bits
+    key = rng.randint(0, nr, n).astype(np.int64)
+    key <<= bits
+    key |= rng.randint(0, ngenes, n)
+    key <<= 8
+    key |= x
+    del x
+    key.sort()
+    pos = key >> 8
+    first = np.empty(n, dtype=bool)
+    first[:1] = True
+    np.not_equal(pos[1:], pos[:-1], out=first[1:])
+    idx = np.flatnonzero(first)
+    counts = np.add.reduceat(key & 255, idx).astype(np.int32) if n else np.zeros(0, np.int32)
+    pos = pos[idx]
+    return (pos >> bits).astype(np.int32) + np.int32(r0), (pos & ((1 << bits) - 1)).astype(np.int32), counts, n
 
-    def draw(i):
-        r0 = starts[i]
-        nr = min(slab_rows, ncells - r0)
-        rng = np.random.RandomState(seed + i)
-        n = int(round(nr * ngenes * density))
-        x = rng.negative_binomial(2, 0.5, n)
-        x[x == 0] = 1
-        np.minimum(x, 255, out=x)                      # P(count > 255) is 2^-250; keeps the count in 8 key bits
-        key = rng.randint(0, nr, n).astype(np.int64)
-        key <<= bits
-        key |= rng.randint(0, ngenes, n)
-        key <<= 8
-        key |= x
-        del x
-        key.sort()
-        pos = key >> 8
-        first = np.empty(n, dtype=bool)
-        first[:1] = True
-        np.not_equal(pos[1:], pos[:-1], out=first[1:])
-        idx = np.flatnonzero(first)
-        counts = np.add.reduceat(key & 255, idx).astype(np.int32)
-        pos = pos[idx]
-        return (pos >> bits).astype(np.int32) + np.int32(r0), (pos & ((1 << bits) - 1)).astype(np.int32), counts
 
-    workers = threads or max(1, min(len(starts), len(os.sched_getaffinity(0)), 32))
+def _draw_slabs(ncells, ngenes, density, seed, slab_rows, which, threads=None):
+    from concurrent.futures import ThreadPoolExecutor
+    which = list(which)
+    workers = threads or max(1, min(len(which), len(os.sched_getaffinity(0)), 32))
+    if not which:
+        return {}
     with ThreadPoolExecutor(max_workers=workers) as pool:
-        parts = list(pool.map(draw, range(len(starts))))
-    row = np.concatenate([p[0] for p in parts])
-    col = np.concatenate([p[1] for p in parts])
-    val = np.concatenate([p[2] for p in parts])
-    del parts
-    X = coo_matrix((val, (row, col)), shape=(ncells, ngenes), dtype=np.int32)
+        parts = list(pool.map(lambda i: _slab_draw(ncells, ngenes, density, seed, slab_rows, i), which))
+    return dict(zip(which, parts))
+
+
+def _coo_of_parts(parts, shape, row_offset=0):
+    order = sorted(parts)
+    cat = lambda j, dt: (np.concatenate([parts[i][j] for i in order]) if order else np.zeros(0, dt))   # noqa: E731
+    row = cat(0, np.int32)
+    if row_offset:
+        row = row - np.int32(row_offset)
+    X = coo_matrix((cat(2, np.int32), (row, cat(1, np.int32))), shape=shape, dtype=np.int32)
     X.has_canonical_format = True
     return X
+
+
+def synthetic_slabs(ncells, ngenes, density, seed, slab_rows=SLAB_ROWS, threads=None):
+    """Generator A for matrices of several 1e8 draws (all of C5: 5e8): the same recipe drawn slab by
+    slab of `slab_rows` cells, one RandomState(seed + slab) and one thread per slab (NumPy releases the
+    GIL in the draws and in sort) -- coo_matrix.sum_duplicates lexsorts 5e8 entries on one core for minutes.  The
+    result is canonical (row-major, unique) and does not depend on the number of threads."""
+    n_slabs = (ncells + slab_rows - 1) // slab_rows
+    return _coo_of_parts(_draw_slabs(ncells, ngenes, density, seed, slab_rows, range(n_slabs), threads),
+                         (ncells, ngenes))
+
+
+def synthetic_slabs_of_rank(ncells, ngenes, density, seed, world, rank, all_reduce, slab_rows=SLAB_ROWS, threads=None):
+    """Rank `rank`'s block of synthetic_slabs(...) under the product's nnz-balanced row partition WITHOUT any rank
+    drawing the whole matrix ("generate per-shard on each GPU's host slice").  Pass 1: rank r draws the
+    r-th of `world` contiguous runs of slabs and contributes their per-row nonzero counts, row sums and column sums; `all_reduce` (a
+    sum over the ranks of a NumPy array) makes them global: the partition (schpf_amd.sharded.row_partition_from_counts)
+    and the marginals the empirical hyperparameters need.  Pass 2: the rank draws the slabs that overlap its rows and
+    that it does not hold yet (the partition is balanced by nonzeros, the runs by rows: a slab or two at the ends),
+    and drops the others.  Per rank: 1/world of the draws plus a few boundary slabs -- not the whole matrix.
+    Returns (X_local, bounds, facts) with facts = {nnz_total, row_sums, col_sums, slabs_drawn, slabs_total, draws}."""
+    from schpf_amd.sharded import row_partition_from_counts
+    n_slabs = (ncells + slab_rows - 1) // slab_rows
+    mine = list(range(n_slabs * rank // world, n_slabs * (rank + 1) // world))   # contiguous: mostly the rank's own rows
+    parts = _draw_slabs(ncells, ngenes, density, seed, slab_rows, mine, threads)
+    drawn, draws = set(mine), sum(p[3] for p in parts.values())
+    row_nnz = np.zeros(ncells, dtype=np.int64)
+    row_sum = np.zeros(ncells, dtype=np.float64)
+    col_sum = np.zeros(ngenes, dtype=np.float64)
+    for r, c, v, _ in parts.values():
+        row_nnz += np.bincount(r, minlength=ncells)
+        row_sum += np.bincount(r, weights=v, minlength=ncells)
+        col_sum += np.bincount(c, weights=v, minlength=ngenes)
+    row_nnz, row_sum, col_sum = all_reduce(row_nnz), all_reduce(row_sum), all_reduce(col_sum)
+    bounds = row_partition_from_counts(row_nnz, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    need = [i for i in range(n_slabs) if i * slab_rows < hi and min((i + 1) * slab_rows, ncells) > lo] if hi > lo else []
+    for i in list(parts):
+        if i not in need:
+            del parts[i]
+    more = _draw_slabs(ncells, ngenes, density, seed, slab_rows, [i for i in need if i not in parts], threads)
+    drawn |= set(more)
+    draws += sum(p[3] for p in more.values())
+    parts.update(more)
+    for i in list(parts):                       # the two boundary slabs: keep the rank's rows only
+        r, c, v, n = parts[i]
+        if r.size and (r[0] < lo or r[-1] >= hi):
+            keep = (r >= lo) & (r < hi)
+            parts[i] = (r[keep], c[keep], v[keep], n)
+    X = _coo_of_parts(parts, (hi - lo, ngenes), row_offset=lo)
+    facts = {"nnz_total": int(row_nnz.sum()), "row_sums": row_sum, "col_sums": col_sum, "slabs_drawn": len(drawn),
+             "slabs_total": n_slabs, "draws": int(draws),
+             "draws_whole_matrix": int(sum(int(round(min(slab_rows, ncells - i * slab_rows) * ngenes * density))
+                                           for i in range(n_slabs)))}
+    return X, bounds, facts
 
 
 def planted_block(ncells, ngenes, K, target_events, seed):
@@ -241,6 +308,38 @@ def init_engine(eng, X, K, dtype, seed=0, whole=None, rows=None):
     return bp, dp, (xi, eta, theta, beta)
 
 
+def init_engine_of_rank(eng, X, K, dtype, row_sums, col_sums, rank, seed=0):
+    """init_engine for a rank that holds ONLY its row block (the per-rank draw of C5): the empirical hyperparameters
+    (reference scHPF_.py:847-879) from the all-reduced marginals of the whole matrix -- bp = ap mean / var of the cell
+    sums, dp = cp mean / var of the gene sums, clipped to bp / 1000 --, eta / beta drawn from one stream on every
+    rank (identical replicas), the rank's xi / theta from a stream of its own.  The same distributions as
+    scHPF._setup's (:49-70, :783-844); not the unsharded fit's draws, which would take drawing all N x K of them on
+    every rank."""
+    from schpf import scHPF
+    from schpf.scHPF_ import HPF_Gamma
+    m = scHPF(K, dtype=dtype)
+    bp = m.ap * np.mean(row_sums) / np.var(row_sums)
+    dp = m.cp * np.mean(col_sums) / np.var(col_sums)
+    if bp > 1000 * dp:
+        dp = bp / 1000
+    make = HPF_Gamma.random_gamma_factory
+    np.random.seed(seed)
+    eta = make((X.shape[1],), m.cp, dp, dtype=dtype)
+    beta = make((X.shape[1], K), m.c, dp, dtype=dtype)
+    np.random.seed(seed + 1 + rank)
+    xi = make((X.shape[0],), m.ap, bp, dtype=dtype)
+    theta = make((X.shape[0], K), m.a, bp, dtype=dtype)
+    xi.vi_shape[:] = m.ap + K * m.a
+    eta.vi_shape[:] = m.cp + K * m.c
+    eng.upload(X)
+    eng.set_hypers(m.a, m.c, bp, dp)
+    eng.set_gamma("xi", xi.vi_shape, xi.vi_rate)
+    eng.set_gamma("theta", theta.vi_shape, theta.vi_rate)
+    eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
+    eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
+    return bp, dp
+
+
 def _oracle_state(orc, X, K, dtype):
     np.random.seed(0)
     bp, dp, st = orc.setup_state(X, K, np.dtype(dtype), 0.3, 1.0, 0.3, 1.0)
@@ -327,8 +426,9 @@ def cpu_baseline(X, K, dtype):
          passes, AVX2 -- the best CPU form this build knows, on the WHOLE matrix, so that the
          GPU/CPU ratio is not flattered by the reference's serial scatter.
 
-    `cores` is the number of threads the reported figure actually ran with; `host` says what the
-    box offers (logical CPUs, affinity, cgroup quota)."""
+    `cores` is what the box lets this process use (affinity mask capped by the cgroup CPU quota), `threads`
+    the team size the reported figure actually ran with; `host` has the raw facts (logical CPUs, affinity,
+    cgroup quota)."""
     from oracle import hpf_oracle as orc
     orc.build()
     host = host_cpus()
@@ -409,7 +509,7 @@ def cpu_baseline(X, K, dtype):
     dt_f, it_f = _time_iterations(lambda: orc.fused_iteration(M, st, 0.3, 0.3, bp, dp, nthreads=fused_threads),
                                   6.0, 10)
     return {
-        "value": value, "unit": "iterations/s", "cores": threads_i, "kind": "port",
+        "value": value, "unit": "iterations/s", "cores": host["usable"], "threads": threads_i, "kind": "port",
         "host": host,
         "sample": "variant (i) numba-structure C oracle (parallel Xphi + serial scatter-adds, the reference's "
                   "execution shape) at %d threads -- the fastest of the team sizes tried on a 1/16 row sample "
@@ -419,7 +519,7 @@ def cpu_baseline(X, K, dtype):
                              host["usable"], how),
         "whole_matrix": bool(whole), "extrapolation_spread": spread, "sample_points": points,
         "fused_openmp": {
-            "value": 1.0 / dt_f, "unit": "iterations/s", "cores": fused_threads, "kind": "port",
+            "value": 1.0 / dt_f, "unit": "iterations/s", "cores": host["usable"], "threads": fused_threads, "kind": "port",
             "sample": "variant (ii) fused OpenMP restatement (exp hoisted, no Xphi, parallel CSR + CSC "
                       "passes, AVX2), WHOLE matrix (nnz %d), %d timed iterations at %d threads -- the fastest of "
                       "the team sizes tried (s per iteration: %s) --, %.3f s/iter"
@@ -602,17 +702,44 @@ def main():
     # ONE matrix for every N: generator A with seed 42 (what BENCH's N = 1 line times).  With N > 1 every rank draws
     # it (deterministic; nothing but the communicator id travels between the ranks) and keeps its block of the
     # product's nnz-balanced row partition -- the split scHPF.fit(X, devices=[...]) makes.
-    if N * G * density > 2e8:           # all of C5: the threaded slab generator (seconds, not minutes)
-        X = synthetic_slabs(N, G, density, seed=42)
-    else:
-        X = synthetic_block(N, G, density, seed=42)
-    nnz_total = int(X.nnz)
-    bounds = row_partition(X, world)
-    whole, my_rows = None, None
-    if world > 1:
+    # The slab-drawn configurations (C5: 5e8 draws, > 12 GB of working set) are drawn PER RANK: no rank holds the whole
+    # matrix, the partition and the hyperparameters' marginals come from all-reduced per-row / per-column sums
+    # (synthetic_slabs_of_rank) -- the same matrix and the same row blocks as the whole-matrix path would give.
+    import resource
+    slab_rows = SLAB_CONFIGS.get(args.config)
+    whole, my_rows, gen_facts = None, None, None
+    t_gen = time.perf_counter()
+    if slab_rows and world > 1:
+        def all_reduce_np(a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            if args.backend == "nccl":
+                t = t.to("cuda:%d" % local_rank)
+            dist.all_reduce(t)
+            return t.cpu().numpy()
+        threads = max(1, len(os.sched_getaffinity(0)) // world)      # the ranks share the box's cores
+        X, bounds, gen_facts = synthetic_slabs_of_rank(N, G, density, 42, world, rank, all_reduce_np, slab_rows, threads)
+        nnz_total = gen_facts["nnz_total"]
         my_rows = (int(bounds[rank]), int(bounds[rank + 1]))
-        whole = X
-        X, _ = take_rows(whole, *my_rows)
+    else:
+        if slab_rows:                       # all of C5: the threaded slab generator (seconds, not minutes)
+            X = synthetic_slabs(N, G, density, seed=42, slab_rows=slab_rows)
+        else:
+            X = synthetic_block(N, G, density, seed=42)
+        nnz_total = int(X.nnz)
+        bounds = row_partition(X, world)
+        if world > 1:
+            my_rows = (int(bounds[rank]), int(bounds[rank + 1]))
+            whole = X
+            X, _ = take_rows(whole, *my_rows)
+    generation = {"seconds": time.perf_counter() - t_gen,
+                  "host_peak_rss_gb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6,
+                  "how": ("per rank: this rank drew %d of %d slabs (%.3f of the whole matrix's %d draws)"
+                          % (gen_facts["slabs_drawn"], gen_facts["slabs_total"],
+                             gen_facts["draws"] / float(max(gen_facts["draws_whole_matrix"], 1)),
+                             gen_facts["draws_whole_matrix"])) if gen_facts
+                         else "the whole matrix on every rank"}
+    if gen_facts:
+        generation.update({k: gen_facts[k] for k in ("slabs_drawn", "slabs_total", "draws", "draws_whole_matrix")})
     n_local = X.shape[0]
 
     # the engine enqueues on a stream of its own; ShardedCAVI orders the collective with it
@@ -620,7 +747,10 @@ def main():
     if sharded:
         eng.hint_sharded()
     t_up = time.perf_counter()
-    init_engine(eng, X, K, dtype, whole=whole, rows=my_rows)
+    if gen_facts:
+        init_engine_of_rank(eng, X, K, dtype, gen_facts["row_sums"], gen_facts["col_sums"], rank)
+    else:
+        init_engine(eng, X, K, dtype, whole=whole, rows=my_rows)
     upload_s = time.perf_counter() - t_up
     del whole
     nnz_local = X.nnz
@@ -694,28 +824,36 @@ def main():
     if use_graph:
         many(args.steps)                # untimed: captures the K-iteration graph the timed call replays
     loss_start = loss_fn()
+    # shader clock under the sweep launches (schpf_profile_clock: workgroup 0 of every launch stamps the shader-cycle
+    # and the constant-rate counters; it works inside a replayed graph too): once over the timed call itself, once
+    # over the eager pass the kernel times come from
     if use_graph:
         fence()
+        eng.profile_clock()             # reset
         t0 = time.perf_counter()
         many(args.steps)                # EXACTLY K iterations, one library call (one hipGraph launch)
         fence()
         elapsed = time.perf_counter() - t0
+        sclk_timed = eng.profile_clock()
         eng.profile(True)               # kernel times for the roofline: a second, eager pass of K iterations
         eng.profile_read()
         for _ in range(args.steps):
             step()
         prof = eng.profile_read()
+        sclk_eager = eng.profile_clock()
         eng.profile(False)
     else:
         eng.profile(True)
         eng.profile_read()
         fence()
+        eng.profile_clock()             # reset
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         elapsed = time.perf_counter() - t0
         prof = eng.profile_read()
+        sclk_timed = sclk_eager = eng.profile_clock()
         eng.profile(False)
     if sharded:
         el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -758,6 +896,20 @@ def main():
     valu_peak = VALU_PEAK_TFLOPS[args.dtype]
     valu_achieved = flops_launch / (sweep_ms * 1e-3) / 1e12 if sweep_ms > 0 else 0.0
     hbm_frac, valu_frac = achieved / HBM_PEAK_GBS, valu_achieved / valu_peak
+    # The sustained clock scales the two on-chip roofs (the HBM roof does not move with it): the vector-FP peak is
+    # quoted at the 2.4 GHz maximum, the LDS delivers 256 B per clock and CU (MI355X_MICROARCH.md, LDS section).
+    sclk_mhz = sclk_eager[0] if sclk_eager[1] > 0 else None       # over the launches the kernel times come from
+    clock_ratio = (sclk_mhz / MAX_CLOCK_MHZ) if sclk_mhz else 1.0
+    valu_frac_at_sclk = valu_frac / clock_ratio
+    n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    sb = eng.sweep_bytes()
+    lds_alg = (sb["lds_read_nonzeros"] + sb["lds_staged_cell"] + sb["lds_staged_gene"]) / per_iter
+    lds_exec = (sb["lds_read_stored_slots"] + sb["lds_staged_cell"] + sb["lds_staged_gene"]) / per_iter
+    lds_peak = n_cu * LDS_BYTES_PER_CLK_PER_CU * (sclk_mhz or MAX_CLOCK_MHZ) * 1e6 / 1e9       # GB/s at the sustained clock
+    lds_achieved = lds_alg / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    lds_frac = lds_achieved / lds_peak if lds_alg else 0.0
+    bound = max((("hbm", hbm_frac), ("valu_fp%d" % (8 * itemsize), valu_frac_at_sclk), ("lds", lds_frac)),
+                key=lambda kv: kv[1])[0]
     # what the kernel issues for it (tile plans): FMA wave-instructions = 2 sides x nnz x 2 KL / (64 / LPC) lane
     # groups per wave; the nonzero slots the plan stores say how many of the executed step halves carry
     # nonzeros; per wave step the f64 paired loop issues ~2 x 2 KL FMAs + 24 other VALU instructions
@@ -780,9 +932,10 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": "%s: synthetic %d cells x %d genes, density %.3f (negative-binomial counts, "
-                        "RandomState(42), the same matrix for every N), nnz %d after summing duplicates, "
+                        "RandomState(42%s), the same matrix for every N), nnz %d after summing duplicates, "
                         "K=%d, one CAVI iteration per step (no loss evaluation inside the step)"
-                        % (args.config.upper(), N, G, density, nnz_total, K),
+                        % (args.config.upper(), N, G, density, " + slab: slabs of %d cells" % slab_rows if slab_rows else "",
+                           nnz_total, K),
             "parallelism": ("cells row-sharded x%d by schpf_amd.sharded.row_partition (nnz-balanced contiguous row "
                             "blocks; this rank: rows %d..%d, nnz %d), one RCCL all-reduce of G*K+K per iteration (%s)"
                             % (world, my_rows[0], my_rows[1], nnz_local,
@@ -795,6 +948,7 @@ def main():
                        % (args.warmup, prewarm_evals, args.prewarm_s))
                       if use_graph else "one library call per iteration, eager launches",
             "plan": info,
+            "generation": generation,
             **({"comm_fallback": "the library's RCCL communicator could not be set up (%s): torch.distributed "
                                  "issues the all-reduce instead, one call per iteration" % comm_fallback}
                if comm_fallback else {}),
@@ -802,7 +956,14 @@ def main():
         "roofline": {
             # the nearer roof of the two below; `achieved` / `peak` / `frac` keep SURVEY 8(d)'s definition
             # (algorithmic bytes per launch / launch time against the HBM peak) whichever one binds
-            "bound": "valu_fp%d" % (8 * itemsize) if valu_frac > hbm_frac else "hbm",
+            "bound": bound,
+            "bound_how": "the largest of hbm_frac, fp%d_valu_frac_at_sclk and lds.frac (the two on-chip roofs at the "
+                         "shader clock measured under the kernel)" % (8 * itemsize),
+            "sclk_mhz": sclk_mhz, "sclk_mhz_timed_call": sclk_timed[0] if sclk_timed[1] > 0 else None,
+            "sclk_how": "schpf_profile_clock: workgroup 0 of every sweep launch reads s_memtime (shader cycles) and "
+                        "s_memrealtime (constant rate) on entry and exit; sclk_mhz averages the %d launches of the eager "
+                        "pass the kernel times come from, sclk_mhz_timed_call the %d launches inside the timed call; "
+                        "max clock %d MHz" % (sclk_eager[1], sclk_timed[1], MAX_CLOCK_MHZ),
             "kernel": ("tile_sweep_dual_kernel (cell-side + gene-side sweep in one launch; algorithmic "
                        "bytes per launch = B_iter" if per_iter == 1 else
                        "tile_sweep_kernel (cell + gene launches; algorithmic bytes per launch = B_iter/2")
@@ -824,6 +985,18 @@ def main():
                         "slot executes every instruction of a nonzero); measured SQ_INSTS_VALU per launch: profiles/",
             },
             "fp%d_valu_frac" % (8 * itemsize): valu_frac,
+            "fp%d_valu_frac_at_sclk" % (8 * itemsize): valu_frac_at_sclk,
+            "lds": {
+                "what": "LDS bytes of the launch against %d CUs x %d B/clk x the measured shader clock: reads = one table "
+                        "row of KP = %d values per nonzero and orientation (2 * nnz * KP * %d B), + the window stagings "
+                        "(LDS writes) the plans schedule (schpf_sweep_bytes)" % (n_cu, LDS_BYTES_PER_CLK_PER_CU,
+                                                                              info["KP"], itemsize),
+                "bytes_per_launch": lds_alg, "read_bytes_per_launch": sb["lds_read_nonzeros"] / per_iter,
+                "staged_bytes_per_launch": (sb["lds_staged_cell"] + sb["lds_staged_gene"]) / per_iter,
+                "bytes_per_launch_incl_padding_slots": lds_exec,
+                "achieved": lds_achieved, "peak": lds_peak, "unit": "GB/s", "frac": lds_frac,
+                "frac_at_max_clock": lds_frac * clock_ratio,
+            },
             "algorithmic_gb_per_launch": b_launch / 1e9, "sweep_launches_per_iteration": per_iter,
             "avg_launch_ms": sweep_ms, "launches": sweeps,
             "timed_with": ("HIP events on the engine's stream around every launch, over a second pass of the same %d "

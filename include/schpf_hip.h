@@ -15,7 +15,8 @@
  *     caller for the duration of the call (nothing is retained);
  *   - `dtype` selects the model precision T: SCHPF_F32 or SCHPF_F64 (the reference's
  *     scHPF(dtype=...) / hpf_numba.py:30,80);  indices are int32 (SciPy COO default);
- *   - every function returns 0 on success, non-zero on failure; schpf_last_error()
+ *   - every function returns 0 on success, non-zero on failure (SCHPF_ERR_NO_MEMORY when the
+ *     device or the host ran out of memory, 1 for everything else); schpf_last_error()
  *     returns a message for the calling thread.  The library never aborts the process;
  *   - one context = one GPU = one host thread at a time.  Work is enqueued on the
  *     context's HIP stream; calls that return data to the host synchronise it.
@@ -41,6 +42,9 @@ extern "C" {
 #define SCHPF_THETA 1
 #define SCHPF_ETA 2
 #define SCHPF_BETA 3
+
+/* status of a call that failed because hipMalloc (or a host allocation of the plan builders) found no memory */
+#define SCHPF_ERR_NO_MEMORY 2
 
 /* element type of the COO values handed to schpf_upload_coo */
 #define SCHPF_VAL_I32 0
@@ -215,6 +219,18 @@ int schpf_stream_handle(schpf_ctx *ctx, void **stream);
  * Reading synchronises the stream and resets the counters. */
 int schpf_profile_enable(schpf_ctx *ctx, int enable);
 int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4]);
+
+/* Shader clock (MHz) the device sustained UNDER the sweep launches on this context since the last call: workgroup 0 of
+ * every tile-plan sweep launch stamps the shader-cycle counter and the constant-rate counter on entry and exit
+ * (sweep_impl.h clock_probe_*); launches = how many launches the figure averages (0: none ran, shader_mhz = 0).
+ * Synchronises the stream and resets the accumulators.  bench.py's roofline.sclk_mhz. */
+int schpf_profile_clock(schpf_ctx *ctx, double *shader_mhz, int64_t *launches);
+
+/* Bytes ONE iteration moves through the LDS and streams from HBM, computed from the tile plans (all zero for the
+ * gather plan): info = {LDS reads of the nonzeros alone (2 * nnz table rows of KP values), LDS reads of every stored
+ * step slot (padding included), LDS writes of the window stagings cell side, gene side, entry-stream bytes of both
+ * plans in HBM, partial-row bytes written, 0, 0}.  bench.py's roofline.lds. */
+int schpf_sweep_bytes(schpf_ctx *ctx, int64_t info[8]);
 
 /* Plan facts for reports: info[0..] = KP, KL, LPC, chunk_len (tile plan: minus the rows per LDS
  * window / ring slot), windows_cell, windows_gene, n_chunks_cell, n_chunks_gene, n_waves_cell,

@@ -20,6 +20,7 @@
  * tests/golden/psi_gammaln.npz.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 

@@ -64,15 +64,36 @@ void FN(orc_xphi)(long nnz, int N, int G, int K, const REAL *x, const int *row, 
 }
 
 /* compute_loading_shape_update, hpf_numba.py:128-156: serial scatter-add of
- * the rows of Xphi by index, on top of the shape prior. */
+ * the rows of Xphi by index, on top of the shape prior.
+ * scatter_threads <= 1: the reference's own serial loop (what bench.py's CPU
+ * baseline times).  scatter_threads > 1 (the parity tests at BASELINE sizes):
+ * thread t owns the destination rows [t*nkeep/T, (t+1)*nkeep/T) and walks ALL
+ * nonzeros in the same order i = 0 .. nnz-1, adding only those that land in
+ * its rows -- every out[j,k] receives the same terms in the same order as in
+ * the serial loop, so the result is the same bits, T times sooner. */
 void FN(orc_shape_update)(long nnz, int K, const REAL *xphi, const int *keep, int nkeep,
-                          double prior, REAL *out)
+                          double prior, REAL *out, int scatter_threads)
 {
     for (long i = 0; i < (long)nkeep * K; ++i) out[i] = (REAL)prior;   /* :151 */
-    for (long i = 0; i < nnz; ++i) {                                     /* :152-155 */
-        REAL *o = out + (size_t)keep[i] * K;
-        const REAL *p = xphi + (size_t)i * K;
-        for (int k = 0; k < K; ++k) o[k] += p[k];
+    if (scatter_threads <= 1) {
+        for (long i = 0; i < nnz; ++i) {                                 /* :152-155 */
+            REAL *o = out + (size_t)keep[i] * K;
+            const REAL *p = xphi + (size_t)i * K;
+            for (int k = 0; k < K; ++k) o[k] += p[k];
+        }
+        return;
+    }
+#pragma omp parallel num_threads(scatter_threads)
+    {
+        const int T = omp_get_num_threads(), t = omp_get_thread_num();
+        const int lo = (int)((long)nkeep * t / T), hi = (int)((long)nkeep * (t + 1) / T);
+        for (long i = 0; i < nnz; ++i) {
+            const int j = keep[i];
+            if (j < lo || j >= hi) continue;
+            REAL *o = out + (size_t)j * K;
+            const REAL *p = xphi + (size_t)i * K;
+            for (int k = 0; k < K; ++k) o[k] += p[k];
+        }
     }
 }
 
@@ -136,12 +157,13 @@ void FN(orc_pois_llh)(long nnz, int N, int G, int K, const REAL *x, const int *r
  *   freeze_genes (scHPF_.py:668,682,697) skips the gene block.
  *   simultaneous (scHPF_.py:666-685): gene updates computed from the OLD theta
  *             but assigned after the cell updates.
+ *   scatter_threads: see orc_shape_update (1 = the reference's serial scatter-adds).
  * eta_shape / xi_shape are the constants of scHPF_.py:616-618. */
 void FN(orc_cavi_iteration)(long nnz, int N, int G, int K, const REAL *x, const int *row,
                             const int *col, double a, double c, double bp, double dp,
                             REAL *xis, REAL *xir, REAL *ths, REAL *thr, REAL *ets, REAL *etr,
                             REAL *bes, REAL *ber, REAL *xphi_ws, int use_given_xphi,
-                            int freeze_genes, int simultaneous, int nthreads)
+                            int freeze_genes, int simultaneous, int nthreads, int scatter_threads)
 {
     if (!use_given_xphi)
         FN(orc_xphi)(nnz, N, G, K, x, row, col, ths, thr, bes, ber, xphi_ws, nthreads);
@@ -151,12 +173,12 @@ void FN(orc_cavi_iteration)(long nnz, int N, int G, int K, const REAL *x, const 
         if (!freeze_genes) {                                             /* :668-673 */
             bvs = (REAL *)malloc(sizeof(REAL) * (size_t)G * K);
             bvr = (REAL *)malloc(sizeof(REAL) * (size_t)G * K);
-            FN(orc_shape_update)(nnz, K, xphi_ws, col, G, c, bvs);
+            FN(orc_shape_update)(nnz, K, xphi_ws, col, G, c, bvs, scatter_threads);
             FN(orc_rate_update)(G, N, K, ets, etr, ths, thr, bvr);
         }
         REAL *tvs = (REAL *)malloc(sizeof(REAL) * (size_t)N * K);         /* :675-680 */
         REAL *tvr = (REAL *)malloc(sizeof(REAL) * (size_t)N * K);
-        FN(orc_shape_update)(nnz, K, xphi_ws, row, N, a, tvs);
+        FN(orc_shape_update)(nnz, K, xphi_ws, row, N, a, tvs, scatter_threads);
         FN(orc_rate_update)(N, G, K, xis, xir, bes, ber, tvr);
         memcpy(ths, tvs, sizeof(REAL) * (size_t)N * K);
         memcpy(thr, tvr, sizeof(REAL) * (size_t)N * K);
@@ -175,7 +197,7 @@ void FN(orc_cavi_iteration)(long nnz, int N, int G, int K, const REAL *x, const 
 
     if (!freeze_genes) {                                                 /* :697-704 */
         REAL *bvr = (REAL *)malloc(sizeof(REAL) * (size_t)G * K);
-        FN(orc_shape_update)(nnz, K, xphi_ws, col, G, c, bes);
+        FN(orc_shape_update)(nnz, K, xphi_ws, col, G, c, bes, scatter_threads);
         FN(orc_rate_update)(G, N, K, ets, etr, ths, thr, bvr);          /* OLD theta */
         memcpy(ber, bvr, sizeof(REAL) * (size_t)G * K);
         free(bvr);
@@ -183,7 +205,7 @@ void FN(orc_cavi_iteration)(long nnz, int N, int G, int K, const REAL *x, const 
     }
     {                                                                    /* :706-714 */
         REAL *tvr = (REAL *)malloc(sizeof(REAL) * (size_t)N * K);
-        FN(orc_shape_update)(nnz, K, xphi_ws, row, N, a, ths);
+        FN(orc_shape_update)(nnz, K, xphi_ws, row, N, a, ths, scatter_threads);
         FN(orc_rate_update)(N, G, K, xis, xir, bes, ber, tvr);          /* NEW beta */
         memcpy(thr, tvr, sizeof(REAL) * (size_t)N * K);
         free(tvr);

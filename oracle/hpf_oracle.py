@@ -111,14 +111,15 @@ def compute_Xphi_data_numpy(x, row, col, theta_shape, theta_rate, beta_shape, be
     return x[:, None] * np.exp(logphi)
 
 
-def compute_loading_shape_update(Xphi_data, X_keep, nkeep, shape_prior):
-    """hpf_numba.py:128-156."""
+def compute_loading_shape_update(Xphi_data, X_keep, nkeep, shape_prior, scatter_threads=1):
+    """hpf_numba.py:128-156.  scatter_threads > 1: the same sums in the same order, destination rows split over
+    threads (cavi_oracle_impl.h orc_shape_update) -- bit-identical to the serial loop."""
     dt = Xphi_data.dtype
     nnz, K = Xphi_data.shape
     out = np.empty((nkeep, K), dtype=dt)
     getattr(lib(), "orc_shape_update" + _suffix(dt))(
         ctypes.c_long(nnz), K, _p(_c(Xphi_data, dt)), _p(_c(X_keep, np.int32)), int(nkeep),
-        ctypes.c_double(shape_prior), _p(out))
+        ctypes.c_double(shape_prior), _p(out), int(scatter_threads))
     return out
 
 
@@ -194,12 +195,15 @@ class State(object):
 
 
 def cavi_iteration(x, row, col, st, a, c, bp, dp, xphi=None, freeze_genes=False,
-                   simultaneous=False, nthreads=1):
+                   simultaneous=False, nthreads=1, scatter_threads=1):
     """One iteration, scHPF_.py:657-714 (non-batched), in place on `st`.
 
     `xphi`: optional (nnz, K) array holding X*phi to use instead of
     compute_Xphi_data (the t==0 random responsibilities, scHPF_.py:652-655).
     All state arrays must share one dtype and be C-contiguous.
+    `scatter_threads` > 1 runs the two scatter-adds (serial in the reference, hpf_numba.py:128) split by
+    destination row -- the same bits, sooner: for the parity tests at BASELINE sizes; bench.py's CPU baseline
+    keeps the reference's serial loops (1).
     """
     dt = st.theta_shape.dtype
     N, K = st.theta_shape.shape
@@ -218,7 +222,8 @@ def cavi_iteration(x, row, col, st, a, c, bp, dp, xphi=None, freeze_genes=False,
         ctypes.c_double(a), ctypes.c_double(c), ctypes.c_double(bp), ctypes.c_double(dp),
         _p(st.xi_shape), _p(st.xi_rate), _p(st.theta_shape), _p(st.theta_rate),
         _p(st.eta_shape), _p(st.eta_rate), _p(st.beta_shape), _p(st.beta_rate),
-        _p(ws), given, int(bool(freeze_genes)), int(bool(simultaneous)), int(nthreads))
+        _p(ws), given, int(bool(freeze_genes)), int(bool(simultaneous)), int(nthreads),
+        int(scatter_threads))
     return st
 
 
@@ -304,7 +309,7 @@ def setup_state(X, K, dtype, a, ap, c, cp, bp=None, dp=None, frozen=None):
 def oracle_fit(X, K, dtype=np.float64, a=0.3, ap=1.0, c=0.3, cp=1.0, bp=None, dp=None,
                min_iter=30, max_iter=1000, check_freq=10, epsilon=0.001,
                better_than_n_ago=5, frozen=None, simultaneous=False, nthreads=1,
-               self_max_iter=None):
+               self_max_iter=None, scatter_threads=1):
     """Restatement of scHPF._fit (scHPF_.py:526-780) for reinit=True, no minibatching.
 
     Uses the global np.random state exactly as the reference does (seed it
@@ -333,11 +338,11 @@ def oracle_fit(X, K, dtype=np.float64, a=0.3, ap=1.0, c=0.3, cp=1.0, bp=None, dp
             xphi = x[:, None] * random_phi
             st64 = st.cast(np.float64)
             cavi_iteration(x, row, col, st64, a, c, bp, dp, xphi=xphi, freeze_genes=freeze,
-                           simultaneous=simultaneous, nthreads=nthreads)
+                           simultaneous=simultaneous, nthreads=nthreads, scatter_threads=scatter_threads)
             st = st64.cast(dtype)
         else:
             cavi_iteration(x, row, col, st, a, c, bp, dp, freeze_genes=freeze,
-                           simultaneous=simultaneous, nthreads=nthreads)
+                           simultaneous=simultaneous, nthreads=nthreads, scatter_threads=scatter_threads)
 
         if t % check_freq == 0:                                   # :718-744
             curr = float(mean_negative_pois_llh(x, row, col, st.theta_shape, st.theta_rate,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "schpf_stream_handle": [_vp, ctypes.POINTER(_vp)],
     "schpf_profile_enable": [_vp, _int],
     "schpf_profile_read": [_vp, _dblp, _i64p],
+    "schpf_profile_clock": [_vp, _dblp, _i64p],
+    "schpf_sweep_bytes": [_vp, _i64p],
     "schpf_plan_info": [_vp, _i64p],
     "schpf_upload_info": [_vp, _i64p],
     "schpf_coo_marginals": [_i64, _vp, _vp, _vp, _int, _int, _int, _vp, _vp],
@@ -76,15 +78,22 @@ HIP_RUNTIME = None
 IPC_NOTE = ""   # set by load() when dmabuf IPC may not be in effect (see there)
 
 
+ERR_NO_MEMORY = 2      # include/schpf_hip.h SCHPF_ERR_NO_MEMORY
+
+
 class SchpfHipError(RuntimeError):
-    pass
+    """A failed library call; `status` is the C function's return value."""
+
+    def __init__(self, msg, status=1):
+        RuntimeError.__init__(self, msg)
+        self.status = status
 
 
 def is_out_of_memory(exc):
-    """True if a library error is HIP's out-of-memory (hipMalloc / graph instantiation) -- the only failure the
+    """True if a library error is "no memory" -- hipErrorOutOfMemory on the device or std::bad_alloc in the host-side
+    plan builders, which the C ABI reports with a status of its own (SCHPF_ERR_NO_MEMORY) -- the only failure the
     callers' "does not fit, try a smaller layout" fallbacks are meant for."""
-    msg = str(exc).lower()
-    return "out of memory" in msg or "hiperroroutofmemory" in msg or "memory allocation" in msg
+    return getattr(exc, "status", None) == ERR_NO_MEMORY
 
 
 def build(force=False):
@@ -190,9 +199,9 @@ def ipc_hint():
 def check(status):
     if status != 0:
         msg = load().schpf_last_error().decode("utf-8", "replace")
-        if "must be" in msg or "out of range" in msg or "unknown" in msg:
+        if status != ERR_NO_MEMORY and ("must be" in msg or "out of range" in msg or "unknown" in msg):
             raise ValueError(msg)
-        raise SchpfHipError(msg)
+        raise SchpfHipError(msg, status)
 
 
 def device_count():

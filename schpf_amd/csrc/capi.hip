@@ -36,7 +36,8 @@ int fail(const char *fmt, ...)
 }
 
 struct HipError : std::runtime_error {
-    using std::runtime_error::runtime_error;
+    hipError_t code;
+    HipError(const std::string &what, hipError_t code_ = hipErrorUnknown) : std::runtime_error(what), code(code_) {}
 };
 
 #define HIPCHK(expr)                                                                         \
@@ -46,15 +47,27 @@ struct HipError : std::runtime_error {
             char b_[512];                                                                    \
             snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
                      __FILE__, __LINE__);                                                    \
-            throw HipError(b_);                                                              \
+            throw HipError(b_, e_);                                                          \
         }                                                                                    \
     } while (0)
 
 template <typename F> int guarded(F &&f)
 {
+    // status SCHPF_ERR_NO_MEMORY: the device (hipErrorOutOfMemory) or the host (std::bad_alloc while building plans) ran
+    // out of memory -- the one failure a caller may answer with a smaller layout; everything else is 1
     try {
         f();
         return 0;
+    } catch (const HipError &e) {
+        g_err = e.what();
+        if (e.code == hipErrorOutOfMemory) (void)hipGetLastError();
+        return e.code == hipErrorOutOfMemory ? SCHPF_ERR_NO_MEMORY : 1;
+    } catch (const schpf::DeviceNoMemory &e) {
+        g_err = e.what();
+        return SCHPF_ERR_NO_MEMORY;
+    } catch (const std::bad_alloc &) {
+        g_err = "out of host memory (std::bad_alloc)";
+        return SCHPF_ERR_NO_MEMORY;
     } catch (const std::exception &e) {
         g_err = e.what();
         return 1;
@@ -262,6 +275,8 @@ struct schpf_ctx {
     virtual void loss_terms(double *llh, double *gl, int64_t *nnz) = 0;
     virtual void plan_info(int64_t info[16]) = 0;
     virtual void upload_info(int64_t info[4]) = 0;
+    virtual void profile_clock(double *shader_mhz, int64_t *launches) = 0;
+    virtual void sweep_bytes(int64_t info[8]) = 0;
     double a = 0.3, c = 0.3, bp = 1.0, dp = 1.0;
     Profiler prof;
 };
@@ -285,6 +300,7 @@ template <typename T> struct Engine final : schpf_ctx {
     TileDev tcell, tgene;                           // tile plans (LDS-staged sweep)
     DevBuf dual_order;                              // merged launch order of both plans' tasks (or empty)
     DevBuf dual_queue;                              // persistent dual launch: {next slot, workgroups done}, self-zeroing
+    DevBuf clock_probe;                             // 5 x u64: shader cycles, constant-rate ticks, 2 start stamps, launches (sweep_impl.h)
     int64_t dual_slots = 0;
     bool use_tile = false, want_tile = true;
     int64_t nnz = 0;
@@ -370,6 +386,7 @@ template <typename T> struct Engine final : schpf_ctx {
         choose_config();
         const size_t s = sizeof(T);
         dual_queue.alloc(2 * sizeof(int), true, stream);
+        clock_probe.alloc(8 * sizeof(unsigned long long), true, stream);
         xi_s.alloc((size_t)N * s); xi_r.alloc((size_t)N * s);
         eta_s.alloc((size_t)G * s); eta_r.alloc((size_t)G * s);
         th_s.alloc((size_t)N * K * s); th_r.alloc((size_t)N * K * s);
@@ -1356,7 +1373,7 @@ template <typename T> struct Engine final : schpf_ctx {
         HIPCHK(hipStreamSynchronize(stream));
     }
 
-    int rows_per_block() const { return 256 / K; }
+    int rows_per_block() const { return schpf::update_rows_per_block(K); }
     int upd_blocks(int n) const
     {
         const int groups = (n + rows_per_block() - 1) / rows_per_block();
@@ -1436,6 +1453,7 @@ template <typename T> struct Engine final : schpf_ctx {
         a.wpb = td.host.wpb;
         a.ring = td.host.ring; a.slot_bytes = td.host.slot16 * 16; a.sync_stage = td.host.sync_stage;
         a.single = td.host.single ? 1 : 0;
+        a.clock_probe = clock_probe.as<unsigned long long>();
         return a;
     }
 
@@ -1729,6 +1747,52 @@ template <typename T> struct Engine final : schpf_ctx {
     {
         info[0] = nnz; info[1] = n_rounded; info[2] = n_zero;
         info[3] = (use_tile ? (tcell.packed ? 1 : 0) : 0) | (rows_ptr.p ? 2 : 0);   // bit 1: a row-sorted copy is kept
+    }
+
+    // Shader clock the chip sustained under the sweep launches since the last read (tile plans; 0 launches: unknown).
+    void profile_clock(double *shader_mhz, int64_t *launches) override
+    {
+        unsigned long long h[5] = {0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h, clock_probe.p, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemsetAsync(clock_probe.p, 0, sizeof h, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        int khz = 0;   // rate of s_memrealtime
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) {
+            (void)hipGetLastError();
+            khz = 100000;
+        }
+        *launches = (int64_t)h[4];
+        *shader_mhz = h[1] ? (double)h[0] / (double)h[1] * (double)khz * 1e-3 : 0.0;
+    }
+
+    // LDS bytes the tasks of a tile plan stage: every (sub-)window of a task's range exactly once -- the half-window
+    // schedule fills all slots at the first epoch and afterwards only the slot the last epoch owned, never beyond the
+    // task's last window (sweep_impl.h, the window loop)
+    int64_t staged_bytes(const TileDev &td, int n_minor) const
+    {
+        const schpf::TilePlanHost &P = td.host;
+        const int nm = td.n_virtual ? td.n_virtual : n_minor;
+        int64_t rows = 0;
+        for (size_t t = 0; t < P.task_w0.size(); ++t)
+            for (int w = P.task_w0[t]; w < P.task_w1[t]; ++w) rows += std::max(0, std::min(P.win_rows, nm - w * P.win_rows));
+        return rows * (int64_t)KP * (int64_t)sizeof(T);
+    }
+    // Bytes one iteration moves through the LDS and streams from HBM, from the plans (tile plans; else zeros):
+    //   [0] LDS reads of the nonzeros alone: every nonzero reads one table row of KP values per orientation
+    //   [1] ... of the stored step slots (padding slots execute the same reads)
+    //   [2] [3] LDS writes of the window stagings, cell / gene side
+    //   [4] entry stream of both plans in HBM   [5] partial rows written
+    void sweep_bytes(int64_t info[8]) override
+    {
+        for (int i = 0; i < 8; ++i) info[i] = 0;
+        if (!use_tile || !have_coo) return;
+        const int64_t row = (int64_t)KP * (int64_t)sizeof(T);
+        info[0] = 2 * nnz * row;
+        info[1] = (tcell.entry_slots + tgene.entry_slots) * row;
+        info[2] = staged_bytes(tcell, G);
+        info[3] = staged_bytes(tgene, N);
+        info[4] = (tcell.entry_slots + tgene.entry_slots) * (tcell.packed ? 4 : 8);
+        info[5] = (tcell.host.n_partial_rows + tgene.host.n_partial_rows) * row;
     }
 
     void plan_info(int64_t info[16]) override
@@ -2063,6 +2127,12 @@ int schpf_profile_read(schpf_ctx *ctx, double ms[4], int64_t launches[4])
         }
         ctx->prof.recs.clear());
 }
+int schpf_profile_clock(schpf_ctx *ctx, double *shader_mhz, int64_t *launches)
+{
+    if (!shader_mhz || !launches) return fail("output pointer is NULL");
+    CTX_CALL(ctx->profile_clock(shader_mhz, launches));
+}
+int schpf_sweep_bytes(schpf_ctx *ctx, int64_t info[8]) { CTX_CALL(ctx->sweep_bytes(info)); }
 int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]) { CTX_CALL(ctx->plan_info(info)); }
 int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]) { CTX_CALL(ctx->upload_info(info)); }
 

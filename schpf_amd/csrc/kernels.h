@@ -56,6 +56,10 @@ template <typename T> struct TileArgs {
     // task_order from queue[0]; queue == nullptr: one workgroup per task
     int *queue;
     int n_tasks, resident;
+    // shader-clock probe (capi.hip profile_clock): workgroup 0 adds the shader cycles (s_memtime) and the constant-rate
+    // ticks (s_memrealtime) of its stay in the launch to probe[0], probe[1], and one to probe[4]; probe[2..3] hold its
+    // start stamps.  nullptr: off.  The dual launch reads the cell-side argument block's pointer
+    unsigned long long *clock_probe;
 };
 
 // Fixed-order sum of n values `stride` apart, four loads in flight (the partial rows of one
@@ -123,6 +127,8 @@ hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, 
                                   int packed, int64_t n_slots, int threads, size_t lds_bytes, int *queue, int resident,
                                   hipStream_t st);
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
+// rows a 256-thread block of the update kernel takes per group (UpdateArgs::rows_per_block must be this)
+int update_rows_per_block(int K);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);
 template <typename T>

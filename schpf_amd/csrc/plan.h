@@ -28,10 +28,15 @@
 #include <sys/mman.h>
 #include <memory>
 #include <new>
+#include <stdexcept>
 #include <utility>
 #include <vector>
 
 namespace schpf {
+
+// hipMalloc found no device memory while a plan was being built (plan_device.hip); the C ABI reports it -- like
+// capi.hip's own allocations and std::bad_alloc -- with the status SCHPF_ERR_NO_MEMORY
+struct DeviceNoMemory : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // std::vector whose resize() does NOT zero-fill: the big per-nonzero arrays of a plan (hundreds of
 // MB) are written exactly once by parallel passes; a value-initialising resize would first-touch

@@ -24,6 +24,7 @@ namespace {
 #define PD_CHECK(expr)                                                                          \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
+        if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); throw DeviceNoMemory(std::string(#expr ": ") + hipGetErrorString(e_)); } \
         if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr ": ") + hipGetErrorString(e_)); \
     } while (0)
 

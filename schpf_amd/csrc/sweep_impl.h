@@ -981,6 +981,27 @@ __device__ __forceinline__ void tile_sweep_task(const TileArgs<T> &a, const int 
     tile_sweep_task_window<T, NV, LPC, MODE, MAXT, PACK, BAL>(a, task);
 }
 
+// Shader clock DURING a sweep launch: workgroup 0 (persistent launches: resident from the first slot until the list is
+// empty, i.e. for the whole launch) stamps the shader-cycle counter (s_memtime; one tick = one shader cycle,
+// MI355X_MICROARCH.md) and the constant-rate counter (s_memrealtime) on entry and adds the differences on exit: the
+// quotient is the clock the chip sustained under THIS kernel's load -- DVFS moves it by +-10 % between boxes and bodies
+// (same guide, "DVFS give-back").  The stamps live in memory, not in registers, across the task loop.
+__device__ __forceinline__ void clock_probe_begin(unsigned long long *p)
+{
+    if (p && blockIdx.x == 0 && threadIdx.x == 0) {
+        p[2] = __builtin_readcyclecounter();
+        p[3] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+__device__ __forceinline__ void clock_probe_end(unsigned long long *p)
+{
+    if (p && blockIdx.x == 0 && threadIdx.x == 0) {
+        p[0] += __builtin_readcyclecounter() - p[2];
+        p[1] += __builtin_amdgcn_s_memrealtime() - p[3];
+        p[4] += 1;
+    }
+}
+
 // launch slot -> task: longest tasks first (plan.h task_order), so the launch has a short tail
 // a.queue: persistent workgroups, as in tile_sweep_dual_kernel below
 template <typename T, int NV, int LPC, int MODE, int MAXT, bool PACK, bool BAL = false>
@@ -988,16 +1009,19 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_kernel(TileArgs<T> a)
 {
     __shared__ int next_slot;
     int slot = blockIdx.x;
+    if (MODE != MODE_RANDOM) clock_probe_begin(a.clock_probe);
     for (;;) {
         const int task = a.task_order ? a.task_order[slot] : slot;
         tile_sweep_task<T, NV, LPC, MODE, MAXT, PACK, BAL>(a, task);
-        if (MODE == MODE_RANDOM || !a.queue) return;
+        if (MODE == MODE_RANDOM) return;
+        if (!a.queue) { clock_probe_end(a.clock_probe); return; }
         __syncthreads();
         if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&a.queue[0], 1);
         __syncthreads();
         slot = next_slot;
         if (slot >= a.n_tasks) break;
     }
+    clock_probe_end(a.clock_probe);
     if (threadIdx.x == 0 && atomicAdd(&a.queue[1], 1) == (int)gridDim.x - 1) {
         a.queue[0] = 0;
         a.queue[1] = 0;
@@ -1021,17 +1045,19 @@ __global__ __launch_bounds__(MAXT) void tile_sweep_dual_kernel(TileArgs<T> a0, T
 {
     __shared__ int next_slot;
     int slot = blockIdx.x;
+    clock_probe_begin(a0.clock_probe);
     for (;;) {
         const int code = order[slot];
         if (code >= 0) tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>(a0, code);
         else tile_sweep_task<T, NV, LPC, MODE_PHI, MAXT, PACK, BAL>(a1, ~code);
-        if (!queue) return;
+        if (!queue) { clock_probe_end(a0.clock_probe); return; }
         __syncthreads();                                   // the window and next_slot are free again
         if (threadIdx.x == 0) next_slot = (int)gridDim.x + atomicAdd(&queue[0], 1);
         __syncthreads();
         slot = next_slot;
         if (slot >= n_slots) break;
     }
+    clock_probe_end(a0.clock_probe);
     if (threadIdx.x == 0 && atomicAdd(&queue[1], 1) == (int)gridDim.x - 1) {
         queue[0] = 0;
         queue[1] = 0;

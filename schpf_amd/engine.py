@@ -266,6 +266,20 @@ class DeviceCAVI(object):
         keys = ("cell_sweep", "gene_sweep", "loss_sweep", "gamma_updates")
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(keys)}
 
+    def profile_clock(self):
+        """(MHz, launches): the shader clock the device sustained under the sweep launches since the last call."""
+        mhz, n = ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._lib.schpf_profile_clock(self._h, ctypes.byref(mhz), ctypes.byref(n)))
+        return mhz.value, n.value
+
+    def sweep_bytes(self):
+        """Bytes one iteration moves through the LDS / streams from HBM, from the tile plans (zeros otherwise)."""
+        info = (ctypes.c_int64 * 8)()
+        _lib.check(self._lib.schpf_sweep_bytes(self._h, info))
+        keys = ("lds_read_nonzeros", "lds_read_stored_slots", "lds_staged_cell", "lds_staged_gene",
+                "hbm_entry_stream", "partial_rows")
+        return dict(zip(keys, [int(v) for v in info]))
+
     def plan_info(self):
         info = (ctypes.c_int64 * 16)()
         _lib.check(self._lib.schpf_plan_info(self._h, info))

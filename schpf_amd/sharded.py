@@ -27,11 +27,17 @@ __all__ = ["row_partition", "take_rows", "ShardedCAVI", "exchange_tensor_of", "T
 
 def row_partition(X, world_size):
     """Contiguous row ranges balanced by stored nonzeros.  Returns world_size+1 bounds."""
-    counts = np.bincount(X.row, minlength=X.shape[0]).astype(np.int64)
+    return row_partition_from_counts(np.bincount(X.row, minlength=X.shape[0]), world_size)
+
+
+def row_partition_from_counts(counts, world_size):
+    """The same partition from the stored nonzeros per row alone (a rank that holds only part of the matrix can
+    take part in computing it: bench.py draws C5 per rank)."""
+    counts = np.asarray(counts).astype(np.int64)
     cum = np.concatenate([[0], np.cumsum(counts)])
     targets = cum[-1] * np.arange(1, world_size) / world_size
     inner = np.searchsorted(cum, targets, side="left")
-    bounds = np.concatenate([[0], inner, [X.shape[0]]]).astype(np.int64)
+    bounds = np.concatenate([[0], inner, [counts.shape[0]]]).astype(np.int64)
     return np.maximum.accumulate(bounds)
 
 

@@ -1,4 +1,5 @@
 """pytest configuration: markers, paths, shared fixtures."""
+import functools
 import os
 import sys
 
@@ -37,6 +38,16 @@ def synthetic_counts(ncells, ngenes, frac, seed=42):
     X = coo_matrix((x, (ci, gi)), (ncells, ngenes), dtype=np.int32)
     X.sum_duplicates()
     return X
+
+
+@functools.lru_cache(maxsize=2)
+def bench_matrix(N, G, dens):
+    """The matrices bench.py times (generator A of SURVEY.md 8(d), seed 42), drawn once per session."""
+    if N * G * dens > 2e8:      # all of C5: bench.py's threaded slab generator (5e8 draws in well under a minute)
+        from bench import synthetic_slabs
+        return synthetic_slabs(N, G, dens, seed=42)
+    from bench import synthetic_block               # bench.py's generator A, same seed: entry for entry
+    return synthetic_block(N, G, dens, seed=42)     # synthetic_counts(...) (tests/test_bench_host.py), faster
 
 
 @pytest.fixture(scope="session")

@@ -38,6 +38,18 @@ def test_version_and_error_string():
 
 
 @pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_memory_is_a_status_of_its_own():
+    """The fall-back chains of the host code ("does not fit: try a smaller layout") react to the C ABI's
+    SCHPF_ERR_NO_MEMORY status -- hipErrorOutOfMemory, a plan builder's failed hipMalloc, std::bad_alloc -- and to
+    nothing else; the message text does not matter."""
+    from schpf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "schpf_hip.h")).read()
+    assert re.search(r"#define\s+SCHPF_ERR_NO_MEMORY\s+%d\b" % _lib.ERR_NO_MEMORY, header)
+    assert _lib.is_out_of_memory(_lib.SchpfHipError("std::bad_alloc", _lib.ERR_NO_MEMORY))
+    assert not _lib.is_out_of_memory(_lib.SchpfHipError("hipMalloc failed: out of memory", 1))
+    assert not _lib.is_out_of_memory(ValueError("out of memory"))
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product raises; it never computes on the host."""
     from schpf_amd import hpf_hip, DeviceCAVI

@@ -548,16 +548,7 @@ def _subproblem_check(oracle, X, st_before, got, a, c, bp, dp, cells, genes, rto
     assert got["theta"][0].dtype == dt
 
 
-import functools
-
-
-@functools.lru_cache(maxsize=2)
-def _bench_matrix(N, G, dens):
-    if N * G * dens > 2e8:      # all of C5: bench.py's threaded slab generator (5e8 draws in well under a minute)
-        from bench import synthetic_slabs
-        return synthetic_slabs(N, G, dens, seed=42)
-    from bench import synthetic_block               # bench.py's generator A, same seed: entry for entry
-    return synthetic_block(N, G, dens, seed=42)     # synthetic_counts(...) (tests/test_bench_host.py), faster
+from conftest import bench_matrix as _bench_matrix   # shared with tests/test_trajectory_gpu.py (drawn once per session)
 
 
 BENCH_SHAPES = [   # the workloads bench.py times (BASELINE.json configs[2] and the per-GPU share of configs[4])

@@ -139,6 +139,29 @@ def test_bench_launches_its_own_ranks():
     assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
 
 
+def test_bench_draws_c5_per_rank():
+    """`bench.py --gpus 2 --config c5-small` (C5 at 1/20 of its cells, drawn slab by slab like C5): no rank draws the
+    whole matrix -- each about half of it plus a boundary slab -- yet the line's nnz is the whole matrix's and the
+    row blocks are the product's partition (synthetic_slabs_of_rank; tests/test_bench_host.py checks the blocks entry
+    for entry).  Both ranks on device 0 over gloo, self-launched."""
+    from bench import synthetic_slabs, CONFIGS, SLAB_CONFIGS
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "c5-small", "--steps", "6", "--warmup", "2",
+                        "--comm", "torch", "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--no-converge",
+                        "--no-traffic"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    N, G, dens, K = CONFIGS["c5-small"]
+    whole = synthetic_slabs(N, G, dens, seed=42, slab_rows=SLAB_CONFIGS["c5-small"])
+    assert "nnz %d " % whole.nnz in line["config"]["workload"]
+    gen = line["config"]["generation"]
+    assert gen["slabs_total"] == 40 and gen["slabs_drawn"] <= 22
+    assert gen["draws"] <= 0.56 * gen["draws_whole_matrix"]
+    assert line["n_gpus"] == 2 and np.isfinite(line["value"]) and line["value"] > 0
+    assert np.isfinite(line["loss_after_steps"]) and line["loss_after_steps"] < line["loss_after_warmup"]
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_self_launch_over_real_devices(world):
     """The driver's N > 1 line if it is NOT wrapped in a launcher: `python bench.py --gpus N` over RCCL."""

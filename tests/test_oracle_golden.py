@@ -144,3 +144,27 @@ def test_fused_cpu_variant_matches_reference_structure(oracle, dtype):
         rtol = 1e-11 if np.dtype(dtype) == np.float64 else 5e-5 * (it + 1)
         for got, want in zip(fused.arrays(), st.arrays()):
             assert_allclose(got, want, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("flags", [{}, {"simultaneous": True}, {"freeze_genes": True}])
+def test_split_scatter_is_the_serial_scatter_bit_for_bit(oracle, dtype, flags):
+    """The parity tests at BASELINE sizes run the oracle's two scatter-adds split by destination row over threads
+    (cavi_oracle_impl.h orc_shape_update, scatter_threads > 1): every sum receives the same terms in the same order as
+    in the reference's serial loop (hpf_numba.py:152-155), so the whole iteration is the same bits."""
+    from conftest import synthetic_counts
+    X = synthetic_counts(700, 333, 0.08, seed=5)
+    perm = np.random.RandomState(1).permutation(X.nnz)       # COO order is not sorted in general
+    x, row, col = X.data[perm], X.row[perm], X.col[perm]
+    K, a, c = 7, 0.3, 0.3
+    np.random.seed(3)
+    bp, dp, st = oracle.setup_state(X, K, np.dtype(dtype), a, 1.0, c, 1.0)
+    serial, split = st.copy(), st.copy()
+    for _ in range(3):
+        oracle.cavi_iteration(x, row, col, serial, a, c, bp, dp, nthreads=2, scatter_threads=1, **flags)
+        oracle.cavi_iteration(x, row, col, split, a, c, bp, dp, nthreads=2, scatter_threads=5, **flags)
+    for got, want in zip(split.arrays(), serial.arrays()):
+        assert np.array_equal(got, want)
+    xphi = oracle.compute_Xphi_data(x, row, col, st.theta_shape, st.theta_rate, st.beta_shape, st.beta_rate)
+    assert np.array_equal(oracle.compute_loading_shape_update(xphi, col, X.shape[1], c, scatter_threads=4),
+                          oracle.compute_loading_shape_update(xphi, col, X.shape[1], c))
