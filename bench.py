@@ -45,6 +45,8 @@ CONFIGS = {
     "c4-shard2": (50_000, 20_000, 0.05, 20),     # ... of --gpus 2
     "c4-shard4": (25_000, 20_000, 0.05, 20),     # ... of --gpus 4
 }
+# the row shards of C3 a rank of `--gpus N` holds, as configurations of their own for one-GPU boxes: (whole, ranks)
+SHARD_OF = {"c4-shard": ("c3", 8), "c4-shard4": ("c3", 4), "c4-shard2": ("c3", 2), "c5-shard": ("c5", 8)}
 HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 # vector (VALU) FMA peaks: FP32 157.3 TFLOP/s (MI355X_MICROARCH.md, chip-level table); FP64 vector is half of it,
 # 78.6 TFLOP/s (public MI355X spec; 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz) -- the sweep has no MFMA work
@@ -772,7 +774,26 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             if args.fail_library_comm:
                 raise RuntimeError("--fail-library-comm")
-            drv = NativeShard(eng, uid[0], rank, world)
+            # ncclCommInitRank is collective: if ONE rank fails before it, the others would wait in it forever and the
+            # run would end without a line -- a watchdog turns that into an error exit after three minutes
+            import threading
+            made = {}
+            def make_shard():
+                try:
+                    made["drv"] = NativeShard(eng, uid[0], rank, world)
+                except Exception as e:      # noqa: BLE001 -- re-raised on the main thread below
+                    made["error"] = e
+            th = threading.Thread(target=make_shard, daemon=True)
+            th.start()
+            th.join(180.0)
+            if th.is_alive():
+                sys.stderr.write("rank %d: the library's communicator did not come up within 180 s (another rank failed "
+                                 "before ncclCommInitRank?); giving up\n" % rank)
+                sys.stderr.flush()
+                os._exit(3)
+            if "error" in made:
+                raise made["error"]
+            drv = made["drv"]
         except Exception as e:   # noqa: BLE001 -- whatever it is, the other driver is the answer
             why = "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([1 if drv is not None else 0], dtype=torch.int32,
@@ -1009,10 +1030,36 @@ def main():
             "iteration_frac_of_hbm_peak": (b_iter / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
         },
         "loss_eval_ms": loss_ms, "loss_eval_samples_ms": [round(v, 4) for v in loss_samples],
+        "loss_pass": {"plan": "gene-major" if sb["loss_side"] else "cell-major", "tasks": sb["loss_tasks"],
+                      "how": "chosen by the library's list-schedule model of the pass (capi.hip loss_tasks / loss_side)"},
         "loss_after_warmup": loss_start, "loss_after_steps": loss_end,
         "iterations_per_s_with_loss_every_10": 10.0 / (10 * ms_per_step * 1e-3 + loss_ms * 1e-3),
         "upload_and_plan_s": upload_s,
     }
+    if rank == 0 and world == 1 and sharded and args.config in SHARD_OF and SHARD_OF[args.config][0] == "c3":
+        # a rank's iteration beside its ideal: the WHOLE matrix on this GPU in the same process, divided by the ranks
+        # (what perfect strong scaling without any exchange would give the rank)
+        eng.close()
+        whole_cfg, ranks = SHARD_OF[args.config]
+        Nw, Gw, dw, Kw = CONFIGS[whole_cfg]
+        Xw = synthetic_block(Nw, Gw, dw, seed=42)
+        with DeviceCAVI(Nw, Gw, Kw, dtype=dtype, device=local_rank) as whole_eng:
+            init_engine(whole_eng, Xw, Kw, dtype)
+            whole_eng.init_phi_device(12345)
+            for _ in range(args.warmup):
+                whole_eng.step()
+            whole_eng.steps(args.steps)                 # captures the graph
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            whole_eng.steps(args.steps)
+            whole_eng.synchronize()
+            whole_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        out["per_rank"] = {"ms": ms_per_step, "ideal_ms": whole_ms / ranks, "whole_matrix_ms": whole_ms, "ranks": ranks,
+                           "speedup_bound_before_the_exchange": whole_ms / ms_per_step,
+                           "how": "this line's ms_per_step (a 1/%d row shard of %s through the sharded driver, one-rank "
+                                  "all-reduce) beside 1/%d of the whole %s matrix's iteration on this GPU in the same "
+                                  "process" % (ranks, whole_cfg.upper(), ranks, whole_cfg.upper())}
+        del Xw
     if rank == 0 and world == 1 and not sharded and not args.no_traffic:
         eng.close()
         live, how = live_traffic(X, K, args.dtype)

@@ -229,7 +229,8 @@ int schpf_profile_clock(schpf_ctx *ctx, double *shader_mhz, int64_t *launches);
 /* Bytes ONE iteration moves through the LDS and streams from HBM, computed from the tile plans (all zero for the
  * gather plan): info = {LDS reads of the nonzeros alone (2 * nnz table rows of KP values), LDS reads of every stored
  * step slot (padding included), LDS writes of the window stagings cell side, gene side, entry-stream bytes of both
- * plans in HBM, partial-row bytes written, 0, 0}.  bench.py's roofline.lds. */
+ * plans in HBM, partial-row bytes written, the plan the loss pass sweeps (0 cell-major, 1 gene-major: the model of
+ * capi.hip loss_tasks / loss_side), the tasks it runs as}.  bench.py's roofline.lds and loss_pass. */
 int schpf_sweep_bytes(schpf_ctx *ctx, int64_t info[8]);
 
 /* Plan facts for reports: info[0..] = KP, KL, LPC, chunk_len (tile plan: minus the rows per LDS

@@ -134,6 +134,7 @@ struct TileDev {
     DevBuf llh_block, llh_w0, llh_w1, llh_stage_end, llh_wave_off, llh_order;
     int64_t n_llh_tasks = 0;
     double llh_model = 0.0;     // modelled length of the loss pass on this plan, in step units (0: unknown)
+    int llh_parts = 1;          // sub-ranges per task the model chose for the loss pass
     DevBuf minor_of;            // balanced windows (plan.h): [n_blocks * n_virtual] table row staged at a window position, or empty
     int n_virtual = 0;
     DevBuf order_dev;           // device-built plans: (major, minor)-sorted position -> caller's COO position
@@ -694,7 +695,8 @@ template <typename T> struct Engine final : schpf_ctx {
             return *std::max_element(load.begin(), load.end());
         };
         int best_parts = 1;
-        double best = model(1);
+        const double uncut = model(1);
+        double best = uncut;
         if (env_int("SCHPF_LOSS_SPLIT", 1))
             for (int parts = 2; parts <= 8; ++parts) {
                 const double m = model(parts);
@@ -703,7 +705,8 @@ template <typename T> struct Engine final : schpf_ctx {
         td.llh_model = best;
         if (env_int("SCHPF_VERBOSE", 0))
             fprintf(stderr, "[schpf_hip]   loss pass on the %d x %d plan: %d sub-range(s) per task, modelled %.0f step units (uncut %.0f)\n",
-                    h.n_major, h.n_minor, best_parts, best, model(1));
+                    h.n_major, h.n_minor, best_parts, best, uncut);
+        td.llh_parts = best_parts;
         if (best_parts <= 1) return;
         std::vector<int32_t> blk, w0s, w1s, ends, order;
         std::vector<int64_t> woff;
@@ -1793,6 +1796,10 @@ template <typename T> struct Engine final : schpf_ctx {
         info[3] = staged_bytes(tgene, N);
         info[4] = (tcell.entry_slots + tgene.entry_slots) * (tcell.packed ? 4 : 8);
         info[5] = (tcell.host.n_partial_rows + tgene.host.n_partial_rows) * row;
+        // what the loss pass will sweep (loss_side, loss_tasks): so that a report can say which plan and cut the model chose
+        const int side = loss_side();
+        info[6] = side;
+        info[7] = (side ? tgene : tcell).n_llh_tasks > 0 ? (side ? tgene : tcell).n_llh_tasks : (side ? tgene : tcell).n_tasks;
     }
 
     void plan_info(int64_t info[16]) override

@@ -11,61 +11,11 @@
 #include <stdint.h>
 #include <algorithm>
 #include <climits>
-#include <cstdlib>
 
 #include "kernels.h"
 #include "special.h"
 
 namespace schpf {
-
-// ------------------------------------------------------------------ special functions
-// psi(x), x > 0: upward recurrence to x >= 10 then the Bernoulli asymptotic series
-// (Cephes psi).  Replaces the SciPy C psi the reference binds (hpf_numba.py:16-18).
-// Within 4e-15 (relative or absolute) of SciPy on [1e-4, 1e6] (tests/test_ops_gpu.py).
-__device__ __forceinline__ double dev_digamma(double x)
-{
-    // sum_{j<n} 1/(x+j) accumulated as one fraction num/den: one division instead of up to ten
-    double num = 0.0, den = 1.0;
-    while (x < 10.0) {
-        num = fma(num, x, den);
-        den *= x;
-        x += 1.0;
-    }
-    const double r = 1.0 / x;
-    const double z = r * r;
-    double p = 8.33333333333333333333E-2;
-    p = p * z - 2.10927960927960927961E-2;
-    p = p * z + 7.57575757575757575758E-3;
-    p = p * z - 4.16666666666666666667E-3;
-    p = p * z + 3.96825396825396825397E-3;
-    p = p * z - 8.33333333333333333333E-3;
-    p = p * z + 8.33333333333333333333E-2;
-    return log(x) - 0.5 * r - z * p - num / den;
-}
-
-// psi(x) - log(rate) with ONE logarithm: the recurrence leaves log(x') with x' >= 10, and log(x') - log(rate) =
-// log(x' / rate) costs a division instead of a second log (~70 instructions of the update kernel, which is bound
-// by its instruction count: profiles/r03/update_kernel_variant.txt).  At least as accurate as the difference of
-// two rounded logarithms.
-__device__ __forceinline__ double dev_digamma_less_log(double x, double rate)
-{
-    double num = 0.0, den = 1.0;
-    while (x < 10.0) {
-        num = fma(num, x, den);
-        den *= x;
-        x += 1.0;
-    }
-    const double r = 1.0 / x;
-    const double z = r * r;
-    double p = 8.33333333333333333333E-2;
-    p = p * z - 2.10927960927960927961E-2;
-    p = p * z + 7.57575757575757575758E-3;
-    p = p * z - 4.16666666666666666667E-3;
-    p = p * z + 3.96825396825396825397E-3;
-    p = p * z - 8.33333333333333333333E-3;
-    p = p * z + 8.33333333333333333333E-2;
-    return log(x / rate) - 0.5 * r - z * p - num / den;
-}
 
 // order-preserving integer image of a float (and back): integer max instead of canonicalising v_max_f64 pairs
 __device__ __forceinline__ int float_order_key(float f)
@@ -84,135 +34,11 @@ __device__ __forceinline__ float float_from_order_key(int k) { return __int_as_f
 //   shape = prior + acc;  rate = E[cap_old] + S_other[k];  cap_rate = cap_prior + sum_k E
 //   E = shape/rate;  L = psi(shape) - log(rate);  Et = exp(L - max_k L)
 // plus per-block column sums of E (the "sum over the other loading" of the other side).
-template <typename T, int SRC>
-__global__ __launch_bounds__(256) void gamma_update_kernel(UpdateArgs<T> a)
-{
-    // [rb][KS2] E (row stride K rounded up to even), [rb][KS4] order keys of L (int; stride K rounded up to 4) -- rows
-    // that ds_read_b128 can walk --, [K] sums of the other side
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int K = a.K, KP = a.KP, rb = a.rows_per_block;
-    const int KS2 = (K + 1) & ~1, KS4 = (K + 3) & ~3;
-    double *sE = lds;
-    int *sKey = reinterpret_cast<int *>(lds + (size_t)rb * KS2);
-    double *sS = lds + (size_t)rb * KS2 + (size_t)rb * KS4 / 2;
-    const int t = threadIdx.x;
-    const int r = t / K, k = t - r * K;
-    const bool lane_on = r < rb;
-    if (SRC != SRC_NONE && a.s_other_nb > 0) {
-        // the other side's column sums from its per-block partials, in a fixed order that is the same
-        // in every block: thread (r, k) takes blocks r, r + rb, ...; then factor k's rb values in turn
-        double p = 0.0;
-        if (lane_on) {   // eight loads in flight: the partials sit in L2, a rolled loop would pay one latency per term
-            const double *__restrict__ src = a.s_other_part + k;
-            const size_t st = (size_t)rb * K;
-            double q[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int b = r;
-            for (; b + 7 * rb < a.s_other_nb; b += 8 * rb) {
-                double v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)b * K + j * st];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) q[j] += v[j];
-            }
-            for (; b < a.s_other_nb; b += rb) q[0] += src[(size_t)b * K];
-            p = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-        }
-        if (lane_on) sE[r * K + k] = p;
-        __syncthreads();
-        if (t < K) {
-            double tot = 0.0;
-            for (int q = 0; q < rb; ++q) tot += sE[q * K + t];
-            sS[t] = tot;
-        }
-        __syncthreads();
-    }
-    const double s_other_k = (SRC != SRC_NONE && lane_on)
-                                 ? (a.s_other_nb > 0 ? sS[k] : (a.s_other_t ? (double)a.s_other_t[k] : a.s_other[k]))
-                                 : 0.0;
-    const int groups = (a.n + rb - 1) / rb;
-    if (lane_on && k == 0) {   // the rows' padding: neutral for the sum and for the maximum
-        for (int q = K; q < KS2; ++q) sE[r * KS2 + q] = 0.0;
-        for (int q = K; q < KS4; ++q) sKey[r * KS4 + q] = INT_MIN;
-    }
-    double csum = 0.0;   // this thread's share of the block's column sum of E: its (r, k) over the groups it takes
-    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const int row = grp * rb + r;
-        const bool on = lane_on && row < a.n;
-        double E = 0.0, L = 0.0;
-        if (on) {
-            double shape, rate;
-            if (SRC == SRC_NONE) {
-                shape = (double)a.shape[(size_t)row * K + k];
-                rate = (double)a.rate[(size_t)row * K + k];
-            } else {
-                double acc = 0.0;
-                if (SRC == SRC_PARTIALS) {
-                    acc = sum_strided(a.partials + (size_t)a.cptr[row] * KP + k, a.cptr[row + 1] - a.cptr[row],
-                                      (size_t)KP);
-                } else if (SRC == SRC_STRIDED) {
-                    acc = sum_strided(a.partials + (size_t)a.pfirst[row] * KP + k, a.pcount[row],
-                                      (size_t)a.pstride * KP);
-                } else {
-                    acc = (double)a.dense[(size_t)row * K + k];
-                }
-                shape = a.prior_shape + acc;
-                rate = (double)a.cap_shape[row] / (double)a.cap_rate[row] + s_other_k;
-                a.shape[(size_t)row * K + k] = (T)shape;
-                a.rate[(size_t)row * K + k] = (T)rate;
-                shape = (double)(T)shape;  // tables follow the stored (rounded) parameters
-                rate = (double)(T)rate;
-            }
-            E = shape / rate;
-            L = dev_digamma_less_log(shape, rate);   // psi in double whatever T is (hpf_numba.py:16-18)
-            a.tab_e[(size_t)row * KP + k] = (T)E;
-            a.tab_log[(size_t)row * KP + k] = (T)L;
-            E = (double)(T)E;
-            L = (double)(T)L;
-            sE[r * KS2 + k] = E;
-            sKey[r * KS4 + k] = float_order_key((float)L);
-        }
-        __syncthreads();
-        if (on) {
-            // every thread of a row walks the row once: the shift of the exponentials (the row's largest L, rounded to
-            // float -- any shift within a few units of the maximum serves, it cancels in phi) and the row's sum of E
-            const double2 *__restrict__ e2 = reinterpret_cast<const double2 *>(sE + r * KS2);
-            const int4 *__restrict__ k4 = reinterpret_cast<const int4 *>(sKey + r * KS4);
-            int mk = INT_MIN;
-            double sum = 0.0;
-#pragma unroll 4
-            for (int q = 0; q < KS2 / 2; ++q) {
-                const double2 v = e2[q];
-                sum += v.x;
-                sum += v.y;
-            }
-#pragma unroll 2
-            for (int q = 0; q < KS4 / 4; ++q) {
-                const int4 v = k4[q];
-                mk = max(mk, max(max(v.x, v.y), max(v.z, v.w)));
-            }
-            a.tab_exp[(size_t)row * KP + k] = (T)exp(L - (double)float_from_order_key(mk));
-            if (k == 0 && SRC != SRC_NONE) a.cap_rate_out[row] = (T)(a.cap_prior_rate + sum);
-        }
-        csum += E;
-        __syncthreads();
-    }
-    // column sums of E over the block's rows: one pass over the rb shares at the end instead of one per group
-    if (lane_on) sE[r * K + k] = csum;
-    __syncthreads();
-    if (t < K) {
-        double c = 0.0;
-        for (int q = 0; q < rb; ++q) c += sE[q * K + t];
-        a.colsum_part[(size_t)blockIdx.x * K + t] = c;
-    }
-}
-
-
-// ---- round 6: the same update at about half the instructions per (row, factor) --------------------------------------
-// What changed against gamma_update_kernel above (kept for the A/B of profiles/r06, SCHPF_UPD=1):
-//   * special.h: the digamma recurrence without its data-dependent loop (two quartics, ~13 instructions instead of ~90
-//     per wave), a series logarithm and exponential (~25 / ~22 instructions instead of libm's ~70 / ~45), and two
-//     Newton reciprocals (1 / rate shared by E = shape / rate and by the logarithm's argument; one for the recurrence
-//     and the asymptotic series together) in place of four IEEE divisions;
+//   * the special functions are special.h's: the digamma recurrence without its data-dependent loop, a series
+//     logarithm and exponential, Newton reciprocals (1 / rate shared by E = shape / rate and by the logarithm's argument)
+//     -- SQ_INSTS_VALU per launch -6 % (-30 % for the table refresh), wave cycles -14 % against the round-3 kernel with
+//     libm's functions and the looped recurrence, at the SAME 26.6 us per launch: the kernel waits on its chain of
+//     dependent memory round trips 60 % of its wave time (profiles/r06/update_kernel_counters_c3_f64.txt);
 //   * WAVE_ROWS: a row's K threads never straddle a wavefront (64 / K rows per wave, rb = 4 * (64 / K) rows per
 //     block: the same 12 at K = 20), so the row maximum / row sum walk through LDS needs no __syncthreads -- LDS
 //     operations of one wave complete in order -- and the four waves of a block run independently inside the group
@@ -223,8 +49,8 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <typename T, int SRC, bool WAVE_ROWS, int MINW>
-__global__ __launch_bounds__(256, MINW) void gamma_update2_kernel(UpdateArgs<T> a)
+template <typename T, int SRC, bool WAVE_ROWS>
+__global__ __launch_bounds__(256, 4) void gamma_update_kernel(UpdateArgs<T> a)   // at least four waves per SIMD (<= 128 VGPRs)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int K = a.K, KP = a.KP, rb = a.rows_per_block;
@@ -639,41 +465,24 @@ __global__ __launch_bounds__(256) void gammaln_array_kernel(const double *__rest
 // never a zero-sized grid: every kernel bounds-checks, an empty problem launches one idle block
 static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 255) / 256) : 1u; }
 
-// SCHPF_UPD=1: the round-3 kernel (A/B of profiles/r06); default: gamma_update2_kernel
-static int update_variant()
-{
-    const char *e = getenv("SCHPF_UPD");   // read per launch: tools/explore.py switches it inside one process
-    return (e && *e) ? atoi(e) : 2;
-}
-static bool update_wave_rows(int K) { return update_variant() >= 2 && K <= 64 && (64 / K) * K >= 56; }
+static bool update_wave_rows(int K) { return K <= 64 && (64 / K) * K >= 56; }
 int update_rows_per_block(int K) { return update_wave_rows(K) ? 4 * (64 / K) : 256 / K; }
 
-template <typename T, bool WR, int MINW> static void launch_update2(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
+template <typename T, bool WR> static void launch_update_t(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
 {
     dim3 block(256);
-    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update2_kernel<T, SRC_NONE, WR, MINW>), grid, block, lds, st, a);
-    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update2_kernel<T, SRC_PARTIALS, WR, MINW>), grid, block, lds, st, a);
-    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update2_kernel<T, SRC_STRIDED, WR, MINW>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gamma_update2_kernel<T, SRC_DENSE, WR, MINW>), grid, block, lds, st, a);
+    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE, WR>), grid, block, lds, st, a);
+    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS, WR>), grid, block, lds, st, a);
+    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED, WR>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE, WR>), grid, block, lds, st, a);
 }
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st)
 {
     const size_t lds = ((size_t)2 * a.rows_per_block * (a.K + 3) + 2 * a.K) * sizeof(double);   // E rows, key rows, sums (padded strides)
-    dim3 grid((unsigned)nblocks), block(256);
-    if (update_variant() >= 2) {
-        if (a.rows_per_block != update_rows_per_block(a.K)) return hipErrorInvalidValue;
-        const int v = update_variant();   // A/B of profiles/r06: 2 = 4 waves per SIMD, 3 = at least 5 (spills), 4 = 6
-        if (update_wave_rows(a.K)) {
-            if (v == 3) launch_update2<T, true, 5>(a, src, grid, lds, st);
-            else if (v == 4) launch_update2<T, true, 6>(a, src, grid, lds, st);
-            else launch_update2<T, true, 4>(a, src, grid, lds, st);
-        } else launch_update2<T, false, 4>(a, src, grid, lds, st);
-        return hipGetLastError();
-    }
-    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE>), grid, block, lds, st, a);
-    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS>), grid, block, lds, st, a);
-    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE>), grid, block, lds, st, a);
+    if (a.rows_per_block != update_rows_per_block(a.K)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblocks);
+    if (update_wave_rows(a.K)) launch_update_t<T, true>(a, src, grid, lds, st);
+    else launch_update_t<T, false>(a, src, grid, lds, st);
     return hipGetLastError();
 }
 

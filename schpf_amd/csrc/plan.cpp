@@ -703,8 +703,9 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
 {
     const int W = P.n_windows, wpb = P.wpb, gpw = P.gpw;
     const int nth = host_threads();
-    // work of a task: its workgroup runs, window by window, as long as its slowest wave (+ a
-    // staging of the window); task_order (longest first) feeds the merged cell+gene launch
+    // work of a task in nonzero-times: its workgroup runs, window by window, as long as its slowest wave (+ a
+    // staging of the window, worth two step slots = four nonzeros; half that per half window); task_order
+    // (longest first) feeds the merged cell+gene launch
     P.task_work.assign((size_t)P.n_tasks, 0);
     parallel_for(P.n_tasks, nth, [&](int64_t t0_, int64_t t1_, int) {
         for (int64_t t = t0_; t < t1_; ++t) {
@@ -713,7 +714,9 @@ int64_t tile_plan_offsets(TilePlanHost &P, std::vector<int64_t> &wave_off)
             for (int w = P.task_w0[(size_t)t]; w < P.task_w1[(size_t)t]; ++w) {
                 int mx = 0;
                 for (int v = 0; v < wpb; ++v) mx = std::max<int>(mx, P.steps[((size_t)b * wpb + v) * W + w]);
-                work += (int64_t)tile_stored_steps(P, mx) + (P.ring > 1 ? 1 : 2);
+                // in the unit the kernel spends its time in: `single` plans run one nonzero at a time (steps count
+                // nonzeros, a stored slot holds two), so a window's fixed cost weighs the same against either kind
+                work += (P.single ? (int64_t)mx : 2 * (int64_t)mx) + (P.ring > 1 ? 2 : 4);
             }
             P.task_work[(size_t)t] = work;
         }
@@ -906,7 +909,8 @@ void build_tile_plan(int64_t nnz, const int32_t *major, const int32_t *minor, co
         });
     }
     for (int e : err)
-        if (e) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
+        if (e) throw std::invalid_argument(P.single ? "a row has more than 65535 nonzeros in one window"
+                                                 : "a row has more than 131070 nonzeros in one window");
 
     const double t3 = now();
     std::vector<int64_t> wave_off;

@@ -507,7 +507,8 @@ void build_tile_plan_device(void *stream, int64_t nnz, const int32_t *d_major, c
         std::vector<uint32_t> steps32(n_steps + 1);
         PD_CHECK(hipMemcpyAsync(steps32.data(), d_steps32.p, (n_steps + 1) * 4, hipMemcpyDeviceToHost, st));
         PD_CHECK(hipStreamSynchronize(st));
-        if (steps32[n_steps]) throw std::invalid_argument("a row has more than 131070 nonzeros in one window");
+        if (steps32[n_steps]) throw std::invalid_argument(P.single ? "a row has more than 65535 nonzeros in one window"
+                                                 : "a row has more than 131070 nonzeros in one window");
         for (size_t i = 0; i < n_steps; ++i) P.steps[i] = (uint16_t)steps32[i];
 
         // ---- 5. host: offsets

@@ -277,7 +277,7 @@ class DeviceCAVI(object):
         info = (ctypes.c_int64 * 8)()
         _lib.check(self._lib.schpf_sweep_bytes(self._h, info))
         keys = ("lds_read_nonzeros", "lds_read_stored_slots", "lds_staged_cell", "lds_staged_gene",
-                "hbm_entry_stream", "partial_rows")
+                "hbm_entry_stream", "partial_rows", "loss_side", "loss_tasks")
         return dict(zip(keys, [int(v) for v in info]))
 
     def plan_info(self):

@@ -197,8 +197,10 @@ class ThreadedShards(object):
             self.close()
             raise
         if self.engines and hasattr(self.engines[0], "upload_info"):
-            # values rounded to float32 in ANY shard, reported once and on the calling thread
-            infos = [e.upload_info() for e in self.engines]
+            # values rounded to float32 in ANY shard, reported once and on the calling thread; the facts are read by the
+            # shard's own pool thread (every library call makes the context's device the thread's current one: read
+            # from here, the caller's current HIP device would be left at the last shard's)
+            infos = self._each(lambda r: self.engines[r].upload_info())
             rounded = sum(i["rounded"] for i in infos)
             if rounded:
                 import warnings
