@@ -55,291 +55,10 @@ MAX_CLOCK_MHZ = 2400            # MI355X_MICROARCH.md chip table: the clock the 
 LDS_BYTES_PER_CLK_PER_CU = 256  # same guide, LDS section: 64 dwords wide per clock
 
 
-def synthetic_block(ncells, ngenes, density, seed):
-    """Generator A of SURVEY.md 8(d) = the reference's test-fixture recipe
-    (tests/conftest.py:14-25): negative-binomial counts at uniform positions, dups summed.
-    Same draws in the same order as the fixture; the duplicates are summed by sorting packed
-    (row, col, count) keys and adding up runs -- entry for entry what coo_matrix.sum_duplicates
-    returns (canonical row-major order), in less than half the time at 1e8 draws (its lexsort)."""
-    rng = np.random.RandomState(seed)
-    nnz = int(round(ncells * ngenes * density))
-    x = rng.negative_binomial(2, 0.5, nnz)
-    x[x == 0] = 1
-    if nnz == 0 or int(x.max()) > 255 or ncells * ngenes >= 2 ** 54:   # the count must fit 8 key bits
-        row = rng.randint(0, ncells, nnz).astype(np.int32)
-        col = rng.randint(0, ngenes, nnz).astype(np.int32)
-        X = coo_matrix((x.astype(np.int32), (row, col)), shape=(ncells, ngenes), dtype=np.int32)
-        X.sum_duplicates()
-        return X
-    bits = max(1, int(ngenes - 1).bit_length())
-    key = rng.randint(0, ncells, nnz).astype(np.int64)
-    key <<= bits
-    key |= rng.randint(0, ngenes, nnz)
-    key <<= 8
-    key |= x
-    del x
-    key.sort()
-    pos = key >> 8
-    first = np.empty(nnz, dtype=bool)
-    first[:1] = True
-    np.not_equal(pos[1:], pos[:-1], out=first[1:])
-    idx = np.flatnonzero(first)
-    counts = np.add.reduceat(key & 255, idx).astype(np.int32)
-    pos = pos[idx]
-    X = coo_matrix((counts, ((pos >> bits).astype(np.int32), (pos & ((1 << bits) - 1)).astype(np.int32))),
-                   shape=(ncells, ngenes), dtype=np.int32)
-    X.has_canonical_format = True
-    return X
-
-
-SLAB_ROWS = 25000       # cells per slab of the slab generator (one RandomState(seed + slab) each)
-SLAB_CONFIGS = {"c5": SLAB_ROWS, "c5-small": 1250}     # configs drawn slab by slab (40 slabs each): ranks draw their own rows
-
-
-def _slab_draw(ncells, ngenes, density, seed, slab_rows, i):
-    """Slab i of generator A drawn slab by slab: rows [i * slab_rows, ...), canonical (row-major, unique),
-    duplicates summed by sorting packed (row, col, count) keys and adding up runs.  Returns (row, col, count, draws)."""
-    bits = max(1, int(ngenes - 1).bit_length())
-    r0 = i * slab_rows
-    nr = min(slab_rows, ncells - r0)
-    rng = np.random.RandomState(seed + i)
-    n = int(round(nr * ngenes * density))
-    x = rng.negative_binomial(2, 0.5, n)
-    x[x == 0] = 1
-    np.minimum(x, 255, out=x)                      # P(count > 255) is 2^-250; keeps the count in 8 key bits
-    key = rng.randint(0, nr, n).astype(np.int64)
-    key <<= bits
-    key |= rng.randint(0, ngenes, n)
-    key <<= 8
-    key |= x
-    del x
-    key.sort()
-    pos = key >> 8
-    first = np.empty(n, dtype=bool)
-    first[:1] = True
-    np.not_equal(pos[1:], pos[:-1], out=first[1:])
-    idx = np.flatnonzero(first)
-    counts = np.add.reduceat(key & 255, idx).astype(np.int32) if n else np.zeros(0, np.int32)
-    pos = pos[idx]
-    return (pos >> bits).astype(np.int32) + np.int32(r0), (pos & ((1 << bits) - 1)).astype(np.int32), counts, n
-
-
-def _draw_slabs(ncells, ngenes, density, seed, slab_rows, which, threads=None):
-    from concurrent.futures import ThreadPoolExecutor
-    which = list(which)
-    workers = threads or max(1, min(len(which), len(os.sched_getaffinity(0)), 32))
-    if not which:
-        return {}
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        parts = list(pool.map(lambda i: _slab_draw(ncells, ngenes, density, seed, slab_rows, i), which))
-    return dict(zip(which, parts))
-
-
-def _coo_of_parts(parts, shape, row_offset=0):
-    order = sorted(parts)
-    cat = lambda j, dt: (np.concatenate([parts[i][j] for i in order]) if order else np.zeros(0, dt))   # noqa: E731
-    row = cat(0, np.int32)
-    if row_offset:
-        row = row - np.int32(row_offset)
-    X = coo_matrix((cat(2, np.int32), (row, cat(1, np.int32))), shape=shape, dtype=np.int32)
-    X.has_canonical_format = True
-    return X
-
-
-def synthetic_slabs(ncells, ngenes, density, seed, slab_rows=SLAB_ROWS, threads=None):
-    """Generator A for matrices of several 1e8 draws (all of C5: 5e8): the same recipe drawn slab by
-    slab of `slab_rows` cells, one RandomState(seed + slab) and one thread per slab (NumPy releases the
-    GIL in the draws and in sort) -- coo_matrix.sum_duplicates lexsorts 5e8 entries on one core for minutes.  The
-    result is canonical (row-major, unique) and does not depend on the number of threads."""
-    n_slabs = (ncells + slab_rows - 1) // slab_rows
-    return _coo_of_parts(_draw_slabs(ncells, ngenes, density, seed, slab_rows, range(n_slabs), threads),
-                         (ncells, ngenes))
-
-
-def synthetic_slabs_of_rank(ncells, ngenes, density, seed, world, rank, all_reduce, slab_rows=SLAB_ROWS, threads=None):
-    """Rank `rank`'s block of synthetic_slabs(...) under the product's nnz-balanced row partition WITHOUT any rank
-    drawing the whole matrix ("generate per-shard on each GPU's host slice").  Pass 1: rank r draws the
-    r-th of `world` contiguous runs of slabs and contributes their per-row nonzero counts, row sums and column sums; `all_reduce` (a
-    sum over the ranks of a NumPy array) makes them global: the partition (schpf_amd.sharded.row_partition_from_counts)
-    and the marginals the empirical hyperparameters need.  Pass 2: the rank draws the slabs that overlap its rows and
-    that it does not hold yet (the partition is balanced by nonzeros, the runs by rows: a slab or two at the ends),
-    and drops the others.  Per rank: 1/world of the draws plus a few boundary slabs -- not the whole matrix.
-    Returns (X_local, bounds, facts) with facts = {nnz_total, row_sums, col_sums, slabs_drawn, slabs_total, draws}."""
-    from schpf_amd.sharded import row_partition_from_counts
-    n_slabs = (ncells + slab_rows - 1) // slab_rows
-    mine = list(range(n_slabs * rank // world, n_slabs * (rank + 1) // world))   # contiguous: mostly the rank's own rows
-    parts = _draw_slabs(ncells, ngenes, density, seed, slab_rows, mine, threads)
-    drawn, draws = set(mine), sum(p[3] for p in parts.values())
-    row_nnz = np.zeros(ncells, dtype=np.int64)
-    row_sum = np.zeros(ncells, dtype=np.float64)
-    col_sum = np.zeros(ngenes, dtype=np.float64)
-    for r, c, v, _ in parts.values():
-        row_nnz += np.bincount(r, minlength=ncells)
-        row_sum += np.bincount(r, weights=v, minlength=ncells)
-        col_sum += np.bincount(c, weights=v, minlength=ngenes)
-    row_nnz, row_sum, col_sum = all_reduce(row_nnz), all_reduce(row_sum), all_reduce(col_sum)
-    bounds = row_partition_from_counts(row_nnz, world)
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    need = [i for i in range(n_slabs) if i * slab_rows < hi and min((i + 1) * slab_rows, ncells) > lo] if hi > lo else []
-    for i in list(parts):
-        if i not in need:
-            del parts[i]
-    more = _draw_slabs(ncells, ngenes, density, seed, slab_rows, [i for i in need if i not in parts], threads)
-    drawn |= set(more)
-    draws += sum(p[3] for p in more.values())
-    parts.update(more)
-    for i in list(parts):                       # the two boundary slabs: keep the rank's rows only
-        r, c, v, n = parts[i]
-        if r.size and (r[0] < lo or r[-1] >= hi):
-            keep = (r >= lo) & (r < hi)
-            parts[i] = (r[keep], c[keep], v[keep], n)
-    X = _coo_of_parts(parts, (hi - lo, ngenes), row_offset=lo)
-    facts = {"nnz_total": int(row_nnz.sum()), "row_sums": row_sum, "col_sums": col_sum, "slabs_drawn": len(drawn),
-             "slabs_total": n_slabs, "draws": int(draws),
-             "draws_whole_matrix": int(sum(int(round(min(slab_rows, ncells - i * slab_rows) * ngenes * density))
-                                           for i in range(n_slabs)))}
-    return X, bounds, facts
-
-
-def planted_block(ncells, ngenes, K, target_events, seed):
-    """Generator B of SURVEY.md 8(d): counts from a planted Gamma-Poisson factor model, so that
-    the reference's stop rule has something to converge to.  x_ig ~ Poisson(sum_k theta_ik
-    beta_gk) is sampled factor by factor: the events of factor k are Poisson(S_theta_k *
-    S_beta_k) many, each landing on cell i with probability theta_ik / S_theta_k and gene g with
-    probability beta_gk / S_beta_k (independent because the rate factorises)."""
-    rng = np.random.RandomState(seed)
-    theta = rng.gamma(0.3, 1.0, (ncells, K)) * rng.gamma(2.0, 0.5, (ncells, 1))
-    beta = rng.gamma(0.3, 1.0, (ngenes, K)) * rng.gamma(2.0, 0.5, (ngenes, 1))
-    st, sb = theta.sum(0), beta.sum(0)
-    scale = target_events / float((st * sb).sum())
-    # one independent stream per factor so that the factors can be drawn by a thread pool (NumPy
-    # releases the GIL in random_sample / searchsorted) and the matrix does not depend on the pool
-    counts_k = rng.poisson(st * sb * scale)
-    seeds = rng.randint(0, 2 ** 31 - 1, K)
-
-    def draw(k):
-        r = np.random.RandomState(seeds[k])
-        n_k = int(counts_k[k])
-        rr = np.searchsorted(np.cumsum(theta[:, k]) / st[k], r.random_sample(n_k)).astype(np.int32)
-        cc = np.searchsorted(np.cumsum(beta[:, k]) / sb[k], r.random_sample(n_k)).astype(np.int32)
-        return rr, cc
-
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=max(1, min(K, (os.cpu_count() or 1)))) as pool:
-        drawn = list(pool.map(draw, range(K)))
-    rows = [d[0] for d in drawn]
-    cols = [d[1] for d in drawn]
-    del drawn
-    row = np.minimum(np.concatenate(rows), ncells - 1)
-    col = np.minimum(np.concatenate(cols), ngenes - 1)
-    # events -> counts: sort (row, col) keys and count runs (what coo_matrix.sum_duplicates does
-    # through a lexsort, several times slower at 1.6e8 events); the result is canonical row-major
-    bits = max(1, int(ngenes - 1).bit_length())
-    key = (row.astype(np.int64) << bits) | col
-    del row, col
-    key.sort()
-    first = np.empty(key.shape[0], dtype=bool)
-    first[:1] = True
-    np.not_equal(key[1:], key[:-1], out=first[1:])
-    idx = np.flatnonzero(first)
-    del first
-    counts = np.diff(idx, append=key.shape[0]).astype(np.int32)
-    key = key[idx]
-    X = coo_matrix((counts, ((key >> bits).astype(np.int32), (key & ((1 << bits) - 1)).astype(np.int32))),
-                   shape=(ncells, ngenes), dtype=np.int32)
-    X.has_canonical_format = True
-    return X
-
-
-def convergence_run(N, G, K, dtype, density):
-    """Wall-clock of a whole scHPF.fit() under the reference's default stop rule (min 30 / max
-    1000 iterations, loss every 10, epsilon 0.001 %; scHPF_.py:234-238, 750-761) on planted data,
-    host COO in, fitted model out: upload + plan build + iterations + loss checks + download."""
-    from schpf import scHPF
-    t_gen = time.perf_counter()
-    X = planted_block(N, G, K, target_events=int(N * G * density * 1.6), seed=42)
-    t_gen = time.perf_counter() - t_gen
-    # the number of iterations the stop rule takes depends on the random start: three seeds, each a
-    # complete fit from the host matrix; the headline is the median wall-clock
-    runs = []
-    for seed in (0, 1, 2):
-        np.random.seed(seed)
-        model = scHPF(K, dtype=dtype, verbose=False)
-        t0 = time.perf_counter()
-        model.fit(X, init="device")
-        wall = time.perf_counter() - t0
-        checks = len(model.loss)
-        runs.append({"seed": seed, "fit_wall_s": wall, "loss_checks": checks,
-                     "iterations": (checks - 1) * model.check_freq + 1,
-                     "first_loss": float(model.loss[0]), "final_loss": float(model.loss[-1])})
-    med = sorted(runs, key=lambda r: r["fit_wall_s"])[1]
-    return {"data": "planted Gamma-Poisson, %d x %d, nnz %d (density %.4f), max count %d"
-                    % (N, G, X.nnz, X.nnz / float(N) / G, int(X.data.max())),
-            "what": "median over 3 random starts of the wall-clock of scHPF.fit(X) -- host COO in, fitted "
-                    "model out: validation, H2D, plan build, t=0 responsibilities, every iteration and loss "
-                    "check, download -- under the reference's default stop rule (min_iter 30, max_iter "
-                    "1000, check_freq 10, epsilon 0.001 %, scHPF_.py:234-238, 750-761)",
-            "unit": "s", "nnz": int(X.nnz), "data_generation_s": t_gen,
-            "fit_wall_s": med["fit_wall_s"], "loss_checks": med["loss_checks"], "iterations": med["iterations"],
-            "first_loss": med["first_loss"], "final_loss": med["final_loss"], "runs": runs}
-
-
-def algorithmic_bytes(nnz, N, G, K, itemsize):
-    """B_iter = 12*nnz + 4*K*s*(N+G) + 2*s*(N+G)."""
-    return 12 * nnz + 4 * K * itemsize * (N + G) + 2 * itemsize * (N + G)
-
-
-def init_engine(eng, X, K, dtype, seed=0, whole=None, rows=None):
-    """Random init exactly as scHPF._setup (reference scHPF_.py:783-844), hypers empirical.  A rank of a
-    sharded run passes the WHOLE matrix as `whole` and its row range as `rows`: hyperparameters and the
-    random start are those of the unsharded fit (what scHPF.fit(X, devices=[...]) does), the rank uploads
-    its block `X` and its slices of xi / theta."""
-    from schpf import scHPF
-    np.random.seed(seed)
-    m = scHPF(K, dtype=dtype)
-    bp, dp, xi, eta, theta, beta = m._setup(X if whole is None else whole, freeze_genes=False, reinit=True)
-    xi.vi_shape[:] = m.ap + K * m.a
-    eta.vi_shape[:] = m.cp + K * m.c
-    eng.upload(X)
-    eng.set_hypers(m.a, m.c, bp, dp)
-    sl = slice(None) if rows is None else slice(int(rows[0]), int(rows[1]))
-    eng.set_gamma("xi", xi.vi_shape[sl], xi.vi_rate[sl])
-    eng.set_gamma("theta", theta.vi_shape[sl], theta.vi_rate[sl])
-    eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
-    eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
-    return bp, dp, (xi, eta, theta, beta)
-
-
-def init_engine_of_rank(eng, X, K, dtype, row_sums, col_sums, rank, seed=0):
-    """init_engine for a rank that holds ONLY its row block (the per-rank draw of C5): the empirical hyperparameters
-    (reference scHPF_.py:847-879) from the all-reduced marginals of the whole matrix -- bp = ap mean / var of the cell
-    sums, dp = cp mean / var of the gene sums, clipped to bp / 1000 --, eta / beta drawn from one stream on every
-    rank (identical replicas), the rank's xi / theta from a stream of its own.  The same distributions as
-    scHPF._setup's (:49-70, :783-844); not the unsharded fit's draws, which would take drawing all N x K of them on
-    every rank."""
-    from schpf import scHPF
-    from schpf.scHPF_ import HPF_Gamma
-    m = scHPF(K, dtype=dtype)
-    bp = m.ap * np.mean(row_sums) / np.var(row_sums)
-    dp = m.cp * np.mean(col_sums) / np.var(col_sums)
-    if bp > 1000 * dp:
-        dp = bp / 1000
-    make = HPF_Gamma.random_gamma_factory
-    np.random.seed(seed)
-    eta = make((X.shape[1],), m.cp, dp, dtype=dtype)
-    beta = make((X.shape[1], K), m.c, dp, dtype=dtype)
-    np.random.seed(seed + 1 + rank)
-    xi = make((X.shape[0],), m.ap, bp, dtype=dtype)
-    theta = make((X.shape[0], K), m.a, bp, dtype=dtype)
-    xi.vi_shape[:] = m.ap + K * m.a
-    eta.vi_shape[:] = m.cp + K * m.c
-    eng.upload(X)
-    eng.set_hypers(m.a, m.c, bp, dp)
-    eng.set_gamma("xi", xi.vi_shape, xi.vi_rate)
-    eng.set_gamma("theta", theta.vi_shape, theta.vi_rate)
-    eng.set_gamma("eta", eta.vi_shape, eta.vi_rate)
-    eng.set_gamma("beta", beta.vi_shape, beta.vi_rate)
-    return bp, dp
+from benchlib.data import (SLAB_CONFIGS, SLAB_ROWS, planted_block, synthetic_block, synthetic_slabs,   # noqa: E402,F401
+                           synthetic_slabs_of_rank)
+from benchlib.setup import algorithmic_bytes, convergence_run, init_engine, init_engine_of_rank   # noqa: E402,F401
+from benchlib.traffic import _pmc_child, live_traffic, static_traffic   # noqa: E402,F401
 
 
 def _oracle_state(orc, X, K, dtype):
@@ -531,92 +250,6 @@ def cpu_baseline(X, K, dtype):
         "note": "CPU baseline = this build's restatements of the reference's path; numba itself cannot be "
                 "installed here (SURVEY.md 8c)",
     }
-
-
-def _pmc_child(path, K, dtype_name, steps):
-    """Body of `bench.py --pmc-child`: the matrix the parent saved, the parent's engine set-up, a few eager
-    iterations -- what rocprofv3 counts one PMC counter over.  Prints nothing the parent parses."""
-    from schpf_amd import DeviceCAVI
-    z = np.load(path)
-    X = coo_matrix((z["data"], (z["row"], z["col"])), shape=tuple(int(v) for v in z["shape"]))
-    dtype = np.float64 if dtype_name == "f64" else np.float32
-    with DeviceCAVI(X.shape[0], X.shape[1], K, dtype=dtype) as eng:
-        init_engine(eng, X, K, dtype)
-        eng.init_phi_device(12345)
-        for _ in range(steps + 2):
-            eng.step()
-        eng.synchronize()
-
-
-def live_traffic(X, K, dtype_name, steps=8):
-    """HBM-side bytes per sweep launch, MEASURED in this run: two extra child processes of this script under
-    `rocprofv3 --pmc` (one counter per pass, never combined with traces; FETCH_SIZE and WRITE_SIZE do not fit
-    one pass, MI355X_MICROARCH.md) iterate the same matrix with the same plans; the per-dispatch averages of
-    the sweep kernel are read from rocprofv3's rocpd database.  bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB:
-    FETCH_SIZE reports half of the bytes of wide coalesced streams on gfx950 (same guide, HBM section;
-    profiles/r01/fetch_size_calibration.txt confirms it for every access shape of this kernel).
-    Returns (GB per launch or None, how)."""
-    import shutil
-    import sqlite3
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    work = tempfile.mkdtemp(prefix="schpf_pmc_", dir="/tmp")
-    try:
-        path = os.path.join(work, "matrix.npz")
-        np.savez(path, data=X.data, row=X.row, col=X.col, shape=np.asarray(X.shape, dtype=np.int64))
-        got = {}
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, counter)
-            cmd = [exe, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", path, "--pmc-k", str(K), "--dtype", dtype_name, "--steps", str(steps)]
-            env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
-            dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
-            if r.returncode != 0 or not dbs:
-                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-200:])
-            con = sqlite3.connect(dbs[0])
-            rows = con.execute("select kernel_name, count(*), avg(value) from counters_collection where "
-                               "counter_name = ? group by kernel_name", (counter,)).fetchall()
-            con.close()
-            sweep = [(n, c, v) for n, c, v in rows if "tile_sweep_dual_kernel" in n or
-                     ("sweep_kernel" in n and "random" not in n and c >= steps)]
-            if not sweep:
-                return None, "no sweep kernel among the counted dispatches"
-            name, count, value = max(sweep, key=lambda t: t[1])
-            got[counter] = (name, int(count), float(value))
-        gb = (2.0 * got["FETCH_SIZE"][2] + got["WRITE_SIZE"][2]) * 1024.0 / 1e9
-        how = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over %d launches of %s in a "
-               "child process on the same matrix and plans; (2 x %.0f + %.0f) KiB per launch (FETCH_SIZE counts half "
-               "of the bytes on gfx950, MI355X_MICROARCH.md)"
-               % (got["FETCH_SIZE"][1], re.sub(r"^void |schpf::|\(.*", "", got["FETCH_SIZE"][0]), got["FETCH_SIZE"][2],
-                  got["WRITE_SIZE"][2]))
-        return gb, how
-    except Exception as exc:       # the bench line must not die of its profiler
-        return None, "live PMC collection failed: %r" % (exc,)
-    finally:
-        shutil.rmtree(work, ignore_errors=True)
-
-
-def static_traffic(config, dtype, info):
-    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (PMC needs its own
-    profiler runs, so this is a STATIC figure): attached only when the plan of this run is the
-    plan the counters were collected on (same entry slots and partial rows), with the commit."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh).get("%s/%s" % (config, dtype))
-    except (OSError, ValueError):
-        return None, None
-    if not rec:
-        return None, None
-    sig = rec.get("plan", {})
-    if any(info.get(k) != v for k, v in sig.items()):
-        return None, "profiles/pmc_traffic.json has counters for another plan of %s/%s (stale): not attached" % (config, dtype)
-    return rec["bytes_per_launch"] / 1e9, ("static: (2*FETCH_SIZE + WRITE_SIZE) per launch in GB from %s, "
-                                           "collected at commit %s on this plan" % (rec.get("source"), rec.get("commit")))
 
 
 def main():

@@ -1377,11 +1377,7 @@ template <typename T> struct Engine final : schpf_ctx {
     }
 
     int rows_per_block() const { return schpf::update_rows_per_block(K); }
-    int upd_blocks(int n) const
-    {
-        const int groups = (n + rows_per_block() - 1) / rows_per_block();
-        return std::max(1, std::min(groups, (int)UPD_BLOCKS));
-    }
+    int upd_blocks(int n) const { return schpf::update_blocks(n, K, (int)UPD_BLOCKS); }
 
     // (re)build E, E[log], exp-shifted tables and column sums from the stored parameters
     void refresh_tables()
@@ -1941,6 +1937,42 @@ bool bad_dtype(int dtype) { return dtype != SCHPF_F32 && dtype != SCHPF_F64; }
 }  // namespace
 
 // ------------------------------------------------------------------------- C ABI
+// SCHPF_BACKTRACE=1 (debugging aid, read when the library is loaded): a SIGSEGV / SIGBUS / SIGABRT prints the native call
+// stack (glibc backtrace: module + offset per frame, resolvable with addr2line against this .so) before the previous
+// handler -- Python's faulthandler under pytest -- runs.  The GPU boxes have no debugger.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+struct sigaction g_prev_segv, g_prev_bus, g_prev_abrt;
+void crash_trace(int sig, siginfo_t *info, void *uctx)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "[schpf_hip] fatal signal, native stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    struct sigaction *prev = sig == SIGSEGV ? &g_prev_segv : sig == SIGBUS ? &g_prev_bus : &g_prev_abrt;
+    sigaction(sig, prev, nullptr);          // hand over: the previous handler (or the default action) sees the re-raised signal
+    raise(sig);
+    (void)info; (void)uctx;
+}
+struct CrashTraceInstaller {
+    CrashTraceInstaller()
+    {
+        const char *e = getenv("SCHPF_BACKTRACE");
+        if (!e || !*e || *e == '0') return;
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_sigaction = crash_trace;
+        sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, &g_prev_segv);
+        sigaction(SIGBUS, &sa, &g_prev_bus);
+        sigaction(SIGABRT, &sa, &g_prev_abrt);
+    }
+} g_crash_trace_installer;
+}  // namespace
+
 extern "C" {
 
 const char *schpf_last_error(void) { return g_err.c_str(); }

@@ -269,8 +269,15 @@ def test_fit_reproduces_reference_trace(amd, fname, dtype, kw, plan_kind):
     for name in ("xi", "theta", "eta", "beta"):
         got = getattr(model, name)
         assert got.vi_shape.dtype == np.dtype(dtype)
+        # float32: 2e-2 on the RAW parameters protects the factors a cell / gene has nearly switched off (shape -> the
+        # prior 0.3, its tiny remainder is a difference of float32 sums after 40-60 iterations); their number is
+        # asserted small right below, and the EXPECTATIONS the north star names are held to 1e-3 further down
         assert_allclose(got.vi_shape, g[name + "_shape"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
         assert_allclose(got.vi_rate, g[name + "_rate"], rtol=2e-2 if f32 else 1e-6, err_msg=name)
+        if f32:
+            for part, want in ((got.vi_shape, g[name + "_shape"]), (got.vi_rate, g[name + "_rate"])):
+                rel = np.abs(part.astype(np.float64) - want.astype(np.float64)) / np.abs(want.astype(np.float64))
+                assert np.mean(rel > 1e-3) <= 0.01, "%s: more than 1 %% of the raw parameters beyond 1e-3" % name
     assert_allclose(model.cell_score(), (g["theta_shape"] / g["theta_rate"])
                     * (g["xi_shape"] / g["xi_rate"])[:, None], rtol=2e-2 if f32 else 1e-6)
     # theta/beta EXPECTATIONS within 1e-6 (f64) / 1e-3 (f32) of the reference's

@@ -1,44 +1,44 @@
 #!/bin/bash
-# Round-end measurement on the GPU box: kernel stats and HBM-traffic counters for the bench command
-# (one rocprofv3 pass per counter, never combined with traces), then plain bench runs.
-#   tools/profile_round.sh <tag>          -> gpurun_out/<tag>_*
-tag=${1:-r01}
-R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out
-mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-converge --no-traffic"
-rm -rf $O/${tag}_stats
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/${tag}_stats -o c3f64 -- $BENCH > $O/${tag}_bench_under_rocprof_c3_f64.json 2> $O/${tag}_stats.log
-python $R/tools/rocpd_summary.py $(find $O/${tag}_stats -name "*.db" | head -1) > $O/${tag}_kernel_stats_c3_f64.txt 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $O/${tag}_pmc_$c
-  timeout 900 rocprofv3 --pmc $c -d $O/${tag}_pmc_$c -o pmc -- $BENCH > /dev/null 2> $O/${tag}_pmc_$c.log
-  python $R/tools/rocpd_summary.py $(find $O/${tag}_pmc_$c -name "*.db" | head -1) | grep -E "counter|sweep|gamma_update" > $O/${tag}_pmc_$c.txt 2>&1
-  rm -rf $O/${tag}_pmc_$c
+# Closing measurement of a round on ONE GPU box (everything a round's profiles/<tag>/ quotes comes from here):
+#   tools/profile_round.sh <tag> [full]          -> gpurun_out/<tag>/
+# always : the bench lines of every configuration (C3 f64 with CPU baselines, live traffic and the convergence fits; C3 f32,
+#          C2, the C5 share, the row shards of C3 through the sharded driver with per_rank / ideal_ms, all of C5), then
+#          kernel stats + HBM traffic + SQ counters of C3 f64, C3 f32 and the C5 share (tools/profile_counters.sh: one
+#          rocprofv3 pass per counter group, never combined with traces);
+# full   : first the build + smoke, the whole `-m gpu` suite and the driver-style line (--steps 20 --warmup 5).
+tag=${1:-r00}; mode=${2:-}
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/$tag; mkdir -p $O
+if [ "$mode" = "full" ]; then
+  python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?"; tail -1 $O/smoke.log
+  timeout 2400 python -m pytest tests/ -x -q -m gpu --durations=15 > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -22 $O/pytest_gpu.log | cut -c1-200
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err; echo "driver-style rc $?"
+fi
+B="--no-cpu-baseline --no-converge --no-traffic"
+python bench.py --steps 100 --warmup 10 > $O/bench_c3_f64.json 2> $O/bench.err
+python bench.py --dtype f32 --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_c3_f32.json 2>> $O/bench.err
+python bench.py --config c2 $B > $O/bench_c2_f64.json 2>> $O/bench.err
+python bench.py --config c2 --dtype f32 $B > $O/bench_c2_f32.json 2>> $O/bench.err
+python bench.py --config c5-shard --steps 60 --warmup 10 $B > $O/bench_c5shard_f64.json 2>> $O/bench.err
+python bench.py --config c5-shard --dtype f32 --steps 60 --warmup 10 $B > $O/bench_c5shard_f32.json 2>> $O/bench.err
+python bench.py --config c5 --steps 20 --warmup 3 $B > $O/bench_c5_whole_f64.json 2>> $O/bench.err
+python bench.py --force-sharded $B > $O/bench_c3_f64_sharded1.json 2>> $O/bench.err
+for s in c4-shard c4-shard4 c4-shard2; do
+  python bench.py --config $s --force-sharded $B > $O/bench_$(echo $s | tr -d '-')_f64_sharded1.json 2>> $O/bench.err
 done
-rm -rf $O/${tag}_stats
-cd $R
-python bench.py > $O/${tag}_bench_c3_f64.json 2> $O/${tag}_bench_c3_f64.err
-python bench.py --dtype f32 --no-cpu-baseline > $O/${tag}_bench_c3_f32.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c2 --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c2_f64.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c5-shard --no-cpu-baseline --no-converge --no-traffic --steps 30 --warmup 5 > $O/${tag}_bench_c5shard_f64.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c3_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c4-shard --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c4-shard4 --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard4_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c4-shard2 --force-sharded --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c4shard2_f64_sharded1.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c5-shard --dtype f32 --no-cpu-baseline --no-converge --no-traffic --steps 30 --warmup 5 > $O/${tag}_bench_c5shard_f32.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c2 --dtype f32 --no-cpu-baseline --no-converge --no-traffic > $O/${tag}_bench_c2_f32.json 2>> $O/${tag}_bench_c3_f64.err
-python bench.py --config c5 --no-cpu-baseline --no-converge --no-traffic --steps 20 --warmup 3 > $O/${tag}_bench_c5_whole_f64.json 2>> $O/${tag}_bench_c3_f64.err
-for f in $O/${tag}_bench_*.json; do echo "== $f"; python - "$f" <<'PY'
+timeout 600 python bench.py --gpus 2 --same-gpu --backend gloo --comm torch --config c2 $B > $O/bench_two_ranks_one_gpu_gloo_c2.json 2>> $O/bench.err; echo "self-launch rc $?"
+for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    r = d["roofline"]
-    print(d["dtype"], "value %.1f" % d["value"], "ms %.4f" % d["ms_per_step"], "frac %.4f" % r["frac"], "launch_ms %.4f" % r["avg_launch_ms"], "upd %.4f" % r["gamma_updates_ms"], "loss_ms %.3f" % d["loss_eval_ms"], d.get("cpu_baseline"))
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+    key = "fp64_valu_frac_at_sclk" if d["dtype"] == "f64" else "fp32_valu_frac_at_sclk"
+    print(sys.argv[1].split("/")[-1], d["dtype"], "value %.1f ms %.4f bound %s sclk %s hbm %.3f valu@sclk %.3f lds %.3f launch_ms %.4f upd %.4f loss_ms %.3f with_loss %.1f per_rank %s" % (
+        d["value"], d["ms_per_step"], r["bound"], r["sclk_mhz"] and round(r["sclk_mhz"]), r["hbm_frac"], r[key], r["lds"]["frac"],
+        r["avg_launch_ms"], r["gamma_updates_ms"], d["loss_eval_ms"], d["iterations_per_s_with_loss_every_10"],
+        d.get("per_rank") and {k: round(v, 4) for k, v in d["per_rank"].items() if isinstance(v, float)}))
 except Exception as e:
-    print("unreadable:", e)
+    print(sys.argv[1], "unreadable:", e)
 PY
 done
-cat $O/${tag}_kernel_stats_c3_f64.txt | cut -c1-150 | head -12
-cat $O/${tag}_pmc_*.txt
+bash tools/profile_counters.sh $tag c3 f64 20
+bash tools/profile_counters.sh $tag c3 f32 20
+bash tools/profile_counters.sh $tag c5-shard f64 20
