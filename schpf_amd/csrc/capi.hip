@@ -1377,7 +1377,11 @@ template <typename T> struct Engine final : schpf_ctx {
     }
 
     int rows_per_block() const { return schpf::update_rows_per_block(K); }
-    int upd_blocks(int n) const { return schpf::update_blocks(n, K, (int)UPD_BLOCKS); }
+    int upd_blocks(int n) const
+    {
+        const int groups = (n + rows_per_block() - 1) / rows_per_block();
+        return std::max(1, std::min(groups, (int)UPD_BLOCKS));
+    }
 
     // (re)build E, E[log], exp-shifted tables and column sums from the stored parameters
     void refresh_tables()

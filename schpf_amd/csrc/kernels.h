@@ -129,8 +129,6 @@ hipError_t launch_tile_sweep_dual(const TileArgs<T> &a0, const TileArgs<T> &a1, 
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st);
 // rows a 256-thread block of the update kernel takes per group (UpdateArgs::rows_per_block must be this)
 int update_rows_per_block(int K);
-// blocks of an update launch over n rows (at most `cap`)
-int update_blocks(int n, int K, int cap);
 hipError_t launch_colsum_reduce(const double *part, int nblocks, int K, double *out, void *mirror,
                                 int mirror_is_f32, hipStream_t st);
 template <typename T>

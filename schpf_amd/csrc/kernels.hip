@@ -11,7 +11,6 @@
 #include <stdint.h>
 #include <algorithm>
 #include <climits>
-#include <cstdlib>
 
 #include "kernels.h"
 #include "special.h"
@@ -50,17 +49,15 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <typename T, int SRC, bool WAVE_ROWS, bool PAIR>
+template <typename T, int SRC, bool WAVE_ROWS>
 __global__ __launch_bounds__(256, 4) void gamma_update_kernel(UpdateArgs<T> a)   // at least four waves per SIMD (<= 128 VGPRs)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int K = a.K, KP = a.KP, rb = a.rows_per_block;
     const int KS2 = (K + 1) & ~1, KS4 = (K + 3) & ~3;
-    // row set u (PAIR: two) = [rb][KS2] E + [rb][KS4] keys, set_stride doubles apart; then the [K] sums
-    const size_t set_stride = (size_t)rb * KS2 + (size_t)rb * KS4 / 2;
     double *sE = lds;
     int *sKey = reinterpret_cast<int *>(lds + (size_t)rb * KS2);
-    double *sS = lds + (PAIR ? 2 : 1) * set_stride;
+    double *sS = lds + (size_t)rb * KS2 + (size_t)rb * KS4 / 2;
     const int t = threadIdx.x;
     int r, k;
     bool lane_on;
@@ -107,53 +104,33 @@ __global__ __launch_bounds__(256, 4) void gamma_update_kernel(UpdateArgs<T> a)  
                                  : 0.0;
     const int groups = (a.n + rb - 1) / rb;
     if (lane_on && k == 0) {   // the rows' padding: neutral for the sum and for the maximum
-        for (int u = 0; u < (PAIR ? 2 : 1); ++u) {
-            for (int q = K; q < KS2; ++q) (sE + u * set_stride)[r * KS2 + q] = 0.0;
-            for (int q = K; q < KS4; ++q) (sKey + u * set_stride * 2)[r * KS4 + q] = INT_MIN;
-        }
+        for (int q = K; q < KS2; ++q) sE[r * KS2 + q] = 0.0;
+        for (int q = K; q < KS4; ++q) sKey[r * KS4 + q] = INT_MIN;
     }
     if (WAVE_ROWS) wave_lds_fence(); else __syncthreads();
     double csum = 0.0;   // this thread's share of the block's column sum of E
-    // One group = rb rows.  PAIR: a block takes two groups per turn (g and g + gridDim) -- the loads of BOTH are issued
-    // before either is computed, so that a wave has twice the memory requests in flight and half as many latency
-    // chains behind one another (the kernel is bound by those chains, not by its arithmetic: DESIGN 9) -- with an LDS row
-    // set of its own per group and one fence pair per turn.
-    struct In { double v0, v1; int row; bool on; };   // v0 = sum of the partial rows (SRC_NONE: shape), v1 = E[capacity] (rate)
-    auto load = [&](int grp) -> In {
-        In in;
-        in.row = grp * rb + r;
-        in.on = lane_on && grp < groups && in.row < a.n;
-        in.v0 = 0.0; in.v1 = 1.0;
-        if (in.on) {
-            const int row = in.row;
-            if (SRC == SRC_NONE) {
-                in.v0 = (double)a.shape[(size_t)row * K + k];
-                in.v1 = (double)a.rate[(size_t)row * K + k];
-            } else {
-                if (SRC == SRC_PARTIALS)
-                    in.v0 = sum_strided(a.partials + (size_t)a.cptr[row] * KP + k, a.cptr[row + 1] - a.cptr[row], (size_t)KP);
-                else if (SRC == SRC_STRIDED)
-                    in.v0 = sum_strided(a.partials + (size_t)a.pfirst[row] * KP + k, a.pcount[row], (size_t)a.pstride * KP);
-                else
-                    in.v0 = (double)a.dense[(size_t)row * K + k];
-                in.v1 = (double)a.cap_shape[row] * fast_rcp((double)a.cap_rate[row]);
-            }
-        }
-        return in;
-    };
-    // parameters, E, E[log]: stored, and the row's E / key(L) into LDS row set `set`; returns L (0 for an idle lane)
-    auto phase1 = [&](const In &in, int set, double &E) -> double {
-        double L = 0.0;
-        E = 0.0;
-        if (in.on) {
-            const int row = in.row;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int row = grp * rb + r;
+        const bool on = lane_on && row < a.n;
+        double E = 0.0, L = 0.0;
+        if (on) {
             double shape, rate;
             if (SRC == SRC_NONE) {
-                shape = in.v0;
-                rate = in.v1;
+                shape = (double)a.shape[(size_t)row * K + k];
+                rate = (double)a.rate[(size_t)row * K + k];
             } else {
-                shape = a.prior_shape + in.v0;
-                rate = in.v1 + s_other_k;
+                double acc = 0.0;
+                if (SRC == SRC_PARTIALS) {
+                    acc = sum_strided(a.partials + (size_t)a.cptr[row] * KP + k, a.cptr[row + 1] - a.cptr[row],
+                                      (size_t)KP);
+                } else if (SRC == SRC_STRIDED) {
+                    acc = sum_strided(a.partials + (size_t)a.pfirst[row] * KP + k, a.pcount[row],
+                                      (size_t)a.pstride * KP);
+                } else {
+                    acc = (double)a.dense[(size_t)row * K + k];
+                }
+                shape = a.prior_shape + acc;
+                rate = (double)a.cap_shape[row] * fast_rcp((double)a.cap_rate[row]) + s_other_k;
                 a.shape[(size_t)row * K + k] = (T)shape;
                 a.rate[(size_t)row * K + k] = (T)rate;
                 shape = (double)(T)shape;  // tables follow the stored (rounded) parameters
@@ -166,45 +143,32 @@ __global__ __launch_bounds__(256, 4) void gamma_update_kernel(UpdateArgs<T> a)  
             a.tab_log[(size_t)row * KP + k] = (T)L;
             E = (double)(T)E;
             L = (double)(T)L;
-            (sE + (size_t)set * set_stride)[r * KS2 + k] = E;
-            (sKey + (size_t)set * set_stride * 2)[r * KS4 + k] = float_order_key((float)L);
+            sE[r * KS2 + k] = E;
+            sKey[r * KS4 + k] = float_order_key((float)L);
         }
-        return L;
-    };
-    // every thread of a row walks the row once: the shift of the exponentials (the row's largest L, rounded to
-    // float -- any shift within a few units of the maximum serves, it cancels in phi) and the row's sum of E
-    auto phase2 = [&](const In &in, int set, double L) {
-        if (!in.on) return;
-        const double2 *__restrict__ e2 = reinterpret_cast<const double2 *>(sE + (size_t)set * set_stride + r * KS2);
-        const int4 *__restrict__ k4 = reinterpret_cast<const int4 *>(sKey + (size_t)set * set_stride * 2 + r * KS4);
-        int mk = INT_MIN;
-        double sum = 0.0;
-#pragma unroll 4
-        for (int q = 0; q < KS2 / 2; ++q) {
-            const double2 v = e2[q];
-            sum += v.x;
-            sum += v.y;
-        }
-#pragma unroll 2
-        for (int q = 0; q < KS4 / 4; ++q) {
-            const int4 v = k4[q];
-            mk = max(mk, max(max(v.x, v.y), max(v.z, v.w)));
-        }
-        a.tab_exp[(size_t)in.row * KP + k] = (T)fast_exp(L - (double)float_from_order_key(mk));
-        if (k == 0 && SRC != SRC_NONE) a.cap_rate_out[in.row] = (T)(a.cap_prior_rate + sum);
-    };
-    for (int grp = blockIdx.x; grp < groups; grp += (PAIR ? 2 : 1) * (int)gridDim.x) {
-        const In in0 = load(grp);
-        In in1;
-        if (PAIR) in1 = load(grp + (int)gridDim.x);
-        double E0, E1 = 0.0, L1 = 0.0;
-        const double L0 = phase1(in0, 0, E0);
-        if (PAIR) L1 = phase1(in1, 1, E1);
         if (WAVE_ROWS) wave_lds_fence(); else __syncthreads();
-        phase2(in0, 0, L0);
-        if (PAIR) phase2(in1, 1, L1);
-        csum += E0;
-        if (PAIR) csum += E1;
+        if (on) {
+            // every thread of a row walks the row once: the shift of the exponentials (the row's largest L, rounded to
+            // float -- any shift within a few units of the maximum serves, it cancels in phi) and the row's sum of E
+            const double2 *__restrict__ e2 = reinterpret_cast<const double2 *>(sE + r * KS2);
+            const int4 *__restrict__ k4 = reinterpret_cast<const int4 *>(sKey + r * KS4);
+            int mk = INT_MIN;
+            double sum = 0.0;
+#pragma unroll 4
+            for (int q = 0; q < KS2 / 2; ++q) {
+                const double2 v = e2[q];
+                sum += v.x;
+                sum += v.y;
+            }
+#pragma unroll 2
+            for (int q = 0; q < KS4 / 4; ++q) {
+                const int4 v = k4[q];
+                mk = max(mk, max(max(v.x, v.y), max(v.z, v.w)));
+            }
+            a.tab_exp[(size_t)row * KP + k] = (T)fast_exp(L - (double)float_from_order_key(mk));
+            if (k == 0 && SRC != SRC_NONE) a.cap_rate_out[row] = (T)(a.cap_prior_rate + sum);
+        }
+        csum += E;
         if (WAVE_ROWS) wave_lds_fence(); else __syncthreads();
     }
     // column sums of E over the block's rows: one pass over the rb shares at the end instead of one per group
@@ -504,43 +468,21 @@ static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 25
 static bool update_wave_rows(int K) { return K <= 64 && (64 / K) * K >= 56; }
 int update_rows_per_block(int K) { return update_wave_rows(K) ? 4 * (64 / K) : 256 / K; }
 
-// SCHPF_UPD_PAIR=1: two groups per turn (A/B of profiles/r06; off until it has been measured)
-static bool update_pairs()
-{
-    const char *e = getenv("SCHPF_UPD_PAIR");
-    return e && *e == '1';
-}
-template <typename T, bool WR, bool PAIR> static void launch_update_t(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
+template <typename T, bool WR> static void launch_update_t(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
 {
     dim3 block(256);
-    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE, WR, PAIR>), grid, block, lds, st, a);
-    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS, WR, PAIR>), grid, block, lds, st, a);
-    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED, WR, PAIR>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE, WR, PAIR>), grid, block, lds, st, a);
-}
-// blocks of an update launch over n rows: every group a block of its own up to `cap`; with two groups per turn half
-// as many, so that the gene side (1 667 groups at C3) is ONE round of resident blocks
-int update_blocks(int n, int K, int cap)
-{
-    const int rb = update_rows_per_block(K);
-    const int groups = (n + rb - 1) / rb;
-    const int want = update_pairs() ? (groups + 1) / 2 : groups;
-    return want < 1 ? 1 : (want > cap ? cap : want);
+    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE, WR>), grid, block, lds, st, a);
+    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS, WR>), grid, block, lds, st, a);
+    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED, WR>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE, WR>), grid, block, lds, st, a);
 }
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st)
 {
-    const bool pair = update_pairs();
-    // E rows, key rows (padded strides; two sets when a block takes two groups per turn), sums
-    const size_t lds = ((size_t)(pair ? 4 : 2) * a.rows_per_block * (a.K + 3) + 2 * a.K) * sizeof(double);
+    const size_t lds = ((size_t)2 * a.rows_per_block * (a.K + 3) + 2 * a.K) * sizeof(double);   // E rows, key rows, sums (padded strides)
     if (a.rows_per_block != update_rows_per_block(a.K)) return hipErrorInvalidValue;
     dim3 grid((unsigned)nblocks);
-    if (update_wave_rows(a.K)) {
-        if (pair) launch_update_t<T, true, true>(a, src, grid, lds, st);
-        else launch_update_t<T, true, false>(a, src, grid, lds, st);
-    } else {
-        if (pair) launch_update_t<T, false, true>(a, src, grid, lds, st);
-        else launch_update_t<T, false, false>(a, src, grid, lds, st);
-    }
+    if (update_wave_rows(a.K)) launch_update_t<T, true>(a, src, grid, lds, st);
+    else launch_update_t<T, false>(a, src, grid, lds, st);
     return hipGetLastError();
 }
 

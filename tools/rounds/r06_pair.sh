@@ -3,7 +3,7 @@
 # computed; half as many blocks) against one group per turn (=0): parity subset, then the A/B on one box.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r06; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?"; tail -1 $O/smoke.log
-SCHPF_BACKTRACE=1 timeout 1200 python -m pytest tests/test_ops_gpu.py tests/test_engine_gpu.py -x -q -m gpu -k "ops or iterations_match_oracle or fused_column or random_problems or fit_reproduces or sharded or steps_call or empty_rows" > $O/pytest_pair.log 2>&1; echo "pytest pair rc $?"; tail -4 $O/pytest_pair.log | cut -c1-200
+SCHPF_UPD_PAIR=1 SCHPF_BACKTRACE=1 timeout 1200 python -m pytest tests/test_ops_gpu.py tests/test_engine_gpu.py -x -q -m gpu -k "ops or iterations_match_oracle or fused_column or random_problems or fit_reproduces or sharded or steps_call or empty_rows" > $O/pytest_pair.log 2>&1; echo "pytest pair rc $?"; tail -4 $O/pytest_pair.log | cut -c1-200
 for cfg in c3 c4-shard c5-shard c2; do
   timeout 600 python tools/explore.py $cfg "dtype=f64,SCHPF_UPD_PAIR=0" "dtype=f64,SCHPF_UPD_PAIR=1" "dtype=f32,SCHPF_UPD_PAIR=0" "dtype=f32,SCHPF_UPD_PAIR=1" "dtype=f64,SCHPF_UPD_PAIR=0" "dtype=f64,SCHPF_UPD_PAIR=1" > $O/ab_update_pairs_$cfg.txt 2>&1
   python - $O/ab_update_pairs_$cfg.txt $cfg <<'PY'
