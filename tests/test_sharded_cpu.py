@@ -136,3 +136,44 @@ def test_fit_over_devices_through_the_estimator(oracle, kw, dtype):
         assert got.vi_shape.shape == getattr(st, name + "_shape").shape
         assert_allclose(got.vi_shape, getattr(st, name + "_shape"), rtol=5e-3 if f32 else 1e-8, err_msg=name)
         assert_allclose(got.vi_rate, getattr(st, name + "_rate"), rtol=5e-3 if f32 else 1e-8, err_msg=name)
+
+
+def _draw_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import synthetic_slabs_of_rank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def all_reduce(a):                       # what bench.py's main() passes in (gloo: host tensors)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        dist.all_reduce(t)
+        return t.numpy()
+
+    X, bounds, facts = synthetic_slabs_of_rank(6000, 900, 0.03, 42, world, rank, all_reduce, slab_rows=250, threads=1)
+    np.savez(os.path.join(out_dir, "draw%d.npz" % rank), row=X.row, col=X.col, data=X.data, shape=np.array(X.shape),
+             bounds=bounds, nnz_total=facts["nnz_total"], draws=facts["draws"], whole=facts["draws_whole_matrix"],
+             row_sums=facts["row_sums"], col_sums=facts["col_sums"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_draw_their_own_rows_over_a_process_group(tmp_path, world):
+    """bench.py --gpus N --config c5 on CPU: `world` gloo processes, each drawing only its part of the slab-drawn
+    matrix (benchlib/data.py synthetic_slabs_of_rank, the two all-reduces through the real process group) -- together
+    they hold exactly the whole-matrix draw split by the product's row_partition, with the global marginals."""
+    from bench import synthetic_slabs
+    mp.spawn(_draw_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    X = synthetic_slabs(6000, 900, 0.03, seed=42, slab_rows=250)
+    want_bounds = row_partition(X, world)
+    parts = [np.load(os.path.join(str(tmp_path), "draw%d.npz" % r)) for r in range(world)]
+    for r, p in enumerate(parts):
+        want, _ = take_rows(X, int(want_bounds[r]), int(want_bounds[r + 1]))
+        assert np.array_equal(p["bounds"], want_bounds) and tuple(p["shape"]) == want.shape
+        assert np.array_equal(p["row"], want.row) and np.array_equal(p["col"], want.col) and np.array_equal(p["data"], want.data)
+        assert int(p["nnz_total"]) == X.nnz
+        assert np.array_equal(p["row_sums"], np.asarray(X.sum(1)).ravel())
+        assert np.array_equal(p["col_sums"], np.asarray(X.sum(0)).ravel())
+        assert int(p["draws"]) <= int(p["whole"]) * (1.0 / world + 3.0 / 24) + 1
