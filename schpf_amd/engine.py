@@ -21,6 +21,12 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def mean_negative(llh, gl, nnz):
+    """-(sum llh) / nnz.  A matrix without stored entries has no mean: NaN, as the reference's np.mean over an empty
+    array (loss.py:167) gives -- not a ZeroDivisionError."""
+    return -(llh - gl) / nnz if nnz else float("nan")
+
+
 class DeviceCAVI(object):
     """CAVI state on one MI355X.
 
@@ -244,7 +250,7 @@ class DeviceCAVI(object):
 
     def mean_negative_pois_llh(self):
         llh, gl, nnz = self.loss_terms()
-        return -(llh - gl) / nnz
+        return mean_negative(llh, gl, nnz)
 
     def synchronize(self):
         _lib.check(self._lib.schpf_synchronize(self._h))

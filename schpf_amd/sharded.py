@@ -22,6 +22,8 @@ import inspect
 
 import numpy as np
 
+from .engine import mean_negative
+
 __all__ = ["row_partition", "take_rows", "ShardedCAVI", "exchange_tensor_of", "ThreadedShards", "NativeShard"]
 
 
@@ -112,7 +114,7 @@ class ShardedCAVI(object):
         t = torch.tensor([llh, gl, float(nnz)], dtype=torch.float64, device=self.exchange.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         llh, gl, nnz = t.tolist()
-        return -(llh - gl) / nnz
+        return mean_negative(llh, gl, nnz)
 
 
 class ThreadedShards(object):
@@ -275,7 +277,7 @@ class ThreadedShards(object):
     def mean_negative_pois_llh(self):
         terms = self._each(lambda r: self.engines[r].loss_terms())   # same process: sum on the host
         llh = sum(t[0] for t in terms); gl = sum(t[1] for t in terms); nnz = sum(t[2] for t in terms)
-        return -(llh - gl) / nnz
+        return mean_negative(llh, gl, nnz)
 
     def close(self):
         engines, self.engines = getattr(self, "engines", []), []
@@ -308,4 +310,4 @@ class NativeShard(object):
 
     def mean_negative_pois_llh(self):
         llh, gl, nnz = self.engine.loss_terms_all()
-        return -(llh - gl) / nnz
+        return mean_negative(llh, gl, nnz)

@@ -422,6 +422,59 @@ def test_persistent_dual_launch_equals_one_workgroup_per_task_bitwise(amd, oracl
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
 
 
+@every_plan
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_matrix_without_stored_entries_keeps_the_priors(amd, oracle, dtype, plan_kind):
+    """The empty input: no stored entry at all.  Every shape stays at its prior, the rates follow from the capacities
+    and the column sums exactly as in the oracle's iteration over zero nonzeros (hpf_numba.py:151 with an empty loop),
+    inside a captured stretch too; the mean loss over no entries is NaN like the reference's np.mean of an empty array."""
+    from scipy.sparse import coo_matrix
+    N, G, K, a, c = 70, 45, 6, 0.3, 0.3
+    X = coo_matrix((np.zeros(0, np.int32), (np.zeros(0, np.int32), np.zeros(0, np.int32))), shape=(N, G))
+    np.random.seed(2)
+    _, _, st = oracle.setup_state(synthetic_counts(N, G, 0.2, seed=1), K, np.dtype(dtype), a, 1.0, c, 1.0)
+    bp, dp = 0.7, 0.02
+    st.xi_shape[:] = 1.0 + K * a
+    st.eta_shape[:] = 1.0 + K * c
+    f32 = np.dtype(dtype) == np.float32
+    with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+        assert eng.nnz == 0
+        for it in range(2):
+            eng.step()
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+            compare_state(eng, st, rtol=(2e-5 * (it + 1)) if f32 else 1e-11)
+        eng.steps(4)
+        for _ in range(4):
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+        compare_state(eng, st, rtol=2e-4 if f32 else 1e-11)
+        ths, _ = eng.get_gamma("theta")
+        bes, _ = eng.get_gamma("beta")
+        assert np.all(ths == np.dtype(dtype).type(a)) and np.all(bes == np.dtype(dtype).type(c))
+        assert np.isnan(eng.mean_negative_pois_llh())
+
+
+@pytest.mark.parametrize("plan_kind,dtype", [("gather", np.float64), ("gather", np.float32), ("tile", np.float32)],
+                         indirect=["plan_kind"])
+def test_largest_supported_number_of_factors(amd, oracle, dtype, plan_kind):
+    """K = 256, the most the update kernel's one-thread-per-(row, factor) mapping takes; 257 is refused.
+    Rows of 2 KiB (float64) are beyond the LDS-staged plan's 1 KiB rows: the library takes the L2-gather plan for them
+    by itself (capi.hip choose_config), which is the plan forced here; float32 rows (1 KiB) run on either."""
+    N, G, K, a, c = 90, 120, 256, 0.3, 0.3
+    X = synthetic_counts(N, G, 0.15, seed=8)
+    bp, dp, st = random_state(oracle, X, K, dtype, seed=12)
+    f32 = np.dtype(dtype) == np.float32
+    with load_engine(amd, X, K, dtype, st, a, c, bp, dp) as eng:
+        for it in range(2):
+            eng.step()
+            oracle.cavi_iteration(X.data, X.row, X.col, st, a, c, bp, dp)
+            compare_state(eng, st, rtol=(2e-5 * (it + 1)) if f32 else 1e-11)
+        want = oracle.mean_negative_pois_llh(X.data, X.row, X.col, st.theta_shape, st.theta_rate,
+                                             st.beta_shape, st.beta_rate)
+        assert_allclose(eng.mean_negative_pois_llh(), want, rtol=1e-5 if f32 else 1e-11)
+    with pytest.raises(ValueError):
+        amd.DeviceCAVI(N, G, 257, dtype=dtype)
+
+
 def test_engine_argument_errors(amd):
     X = synthetic_counts(50, 60, 0.1)
     with pytest.raises(ValueError):
