@@ -49,8 +49,13 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <typename T, int SRC, bool WAVE_ROWS>
-__global__ __launch_bounds__(256, 4) void gamma_update_kernel(UpdateArgs<T> a)   // at least four waves per SIMD (<= 128 VGPRs)
+// MINW: waves per SIMD the register allocation aims at.  8 (61 VGPRs; the series constants are scalar operands, special.h
+// fma_c: before that 114): all 2048 blocks of a launch resident at once -- C3 f64 updates 0.0604 -> 0.0545 ms, the C5
+// share 0.152 -> 0.130.  4 (69 VGPRs = seven waves) for the small problems whose blocks sum the other side's per-block
+// column sums themselves (s_other_nb > 0: sixteen loads in flight in the prologue): C2 0.0178 vs 0.0189 at 8
+// (profiles/r06/ab_update_waves.txt).
+template <typename T, int SRC, bool WAVE_ROWS, int MINW>
+__global__ __launch_bounds__(256, MINW) void gamma_update_kernel(UpdateArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int K = a.K, KP = a.KP, rb = a.rows_per_block;
@@ -468,13 +473,18 @@ static inline unsigned blocks_for(int64_t n) { return n > 0 ? (unsigned)((n + 25
 static bool update_wave_rows(int K) { return K <= 64 && (64 / K) * K >= 56; }
 int update_rows_per_block(int K) { return update_wave_rows(K) ? 4 * (64 / K) : 256 / K; }
 
-template <typename T, bool WR> static void launch_update_t(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
+template <typename T, bool WR, int MINW> static void launch_update_w(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
 {
     dim3 block(256);
-    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE, WR>), grid, block, lds, st, a);
-    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS, WR>), grid, block, lds, st, a);
-    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED, WR>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE, WR>), grid, block, lds, st, a);
+    if (src == SRC_NONE) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_NONE, WR, MINW>), grid, block, lds, st, a);
+    else if (src == SRC_PARTIALS) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_PARTIALS, WR, MINW>), grid, block, lds, st, a);
+    else if (src == SRC_STRIDED) hipLaunchKernelGGL((gamma_update_kernel<T, SRC_STRIDED, WR, MINW>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((gamma_update_kernel<T, SRC_DENSE, WR, MINW>), grid, block, lds, st, a);
+}
+template <typename T, bool WR> static void launch_update_t(const UpdateArgs<T> &a, int src, dim3 grid, size_t lds, hipStream_t st)
+{
+    if (a.s_other_nb > 0) launch_update_w<T, WR, 4>(a, src, grid, lds, st);
+    else launch_update_w<T, WR, 8>(a, src, grid, lds, st);
 }
 template <typename T> hipError_t launch_gamma_update(const UpdateArgs<T> &a, int src, int nblocks, hipStream_t st)
 {

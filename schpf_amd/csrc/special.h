@@ -20,6 +20,21 @@
 
 namespace schpf {
 
+// a * b + C for a compile-time constant C: on the device one v_fma_f64 that reads C from a scalar register pair.  Left to
+// itself hipcc (ROCm 7.2, gfx950: no literal operands in VOP3) keeps the ~45 double constants of the series below in
+// VECTOR registers or rebuilds them with two v_mov_b32 per use and copies them into the accumulator of a v_fmac: three to
+// four VALU instructions per Horner step, a third of the update kernel's instructions; a scalar operand costs SALU moves.
+SCHPF_SF double fma_c(double a, double b, double C)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(C));
+    return r;
+#else
+    return std::fma(a, b, C);
+#endif
+}
+
 // 1 / x for a normal x whose reciprocal is normal: hardware seed (~2^-24 on gfx950) + two Newton steps (error squared
 // twice: below the rounding of the last fma) -- five instructions where the IEEE division sequence takes ~15
 SCHPF_SF double fast_rcp(double x)
@@ -55,15 +70,15 @@ SCHPF_SF double fast_log(double z)
     const double s = (m - 1.0) * fast_rcp(m + 1.0);
     const double s2 = s * s;
     double p = 1.0 / 21.0;
-    p = std::fma(p, s2, 1.0 / 19.0);
-    p = std::fma(p, s2, 1.0 / 17.0);
-    p = std::fma(p, s2, 1.0 / 15.0);
-    p = std::fma(p, s2, 1.0 / 13.0);
-    p = std::fma(p, s2, 1.0 / 11.0);
-    p = std::fma(p, s2, 1.0 / 9.0);
-    p = std::fma(p, s2, 1.0 / 7.0);
-    p = std::fma(p, s2, 1.0 / 5.0);
-    p = std::fma(p, s2, 1.0 / 3.0);
+    p = fma_c(p, s2, 1.0 / 19.0);
+    p = fma_c(p, s2, 1.0 / 17.0);
+    p = fma_c(p, s2, 1.0 / 15.0);
+    p = fma_c(p, s2, 1.0 / 13.0);
+    p = fma_c(p, s2, 1.0 / 11.0);
+    p = fma_c(p, s2, 1.0 / 9.0);
+    p = fma_c(p, s2, 1.0 / 7.0);
+    p = fma_c(p, s2, 1.0 / 5.0);
+    p = fma_c(p, s2, 1.0 / 3.0);
     const double two_s = s + s;
     const double lm = std::fma(two_s * s2, p, two_s);           // log m
     const double ed = (double)e;
@@ -84,16 +99,16 @@ SCHPF_SF double fast_exp(double d)
     double r = std::fma(-n, 6.93147180369123816490e-01, d);     // fdlibm's ln2HI / ln2LO: n * ln2HI is exact
     r = std::fma(-n, 1.90821492927058770002e-10, r);
     double p = 1.0 / 6227020800.0;
-    p = std::fma(p, r, 1.0 / 479001600.0);
-    p = std::fma(p, r, 1.0 / 39916800.0);
-    p = std::fma(p, r, 1.0 / 3628800.0);
-    p = std::fma(p, r, 1.0 / 362880.0);
-    p = std::fma(p, r, 1.0 / 40320.0);
-    p = std::fma(p, r, 1.0 / 5040.0);
-    p = std::fma(p, r, 1.0 / 720.0);
-    p = std::fma(p, r, 1.0 / 120.0);
-    p = std::fma(p, r, 1.0 / 24.0);
-    p = std::fma(p, r, 1.0 / 6.0);
+    p = fma_c(p, r, 1.0 / 479001600.0);
+    p = fma_c(p, r, 1.0 / 39916800.0);
+    p = fma_c(p, r, 1.0 / 3628800.0);
+    p = fma_c(p, r, 1.0 / 362880.0);
+    p = fma_c(p, r, 1.0 / 40320.0);
+    p = fma_c(p, r, 1.0 / 5040.0);
+    p = fma_c(p, r, 1.0 / 720.0);
+    p = fma_c(p, r, 1.0 / 120.0);
+    p = fma_c(p, r, 1.0 / 24.0);
+    p = fma_c(p, r, 1.0 / 6.0);
     p = std::fma(p, r, 0.5);
     p = std::fma(p, r, 1.0);
     p = std::fma(p, r, 1.0);
@@ -115,14 +130,14 @@ SCHPF_SF double digamma_less_log(double x, double inv_rate)
     const double xs = big ? 1.0 : x;
     const double u = std::fma(xs, xs, 9.0 * xs);
     double P = u + 60.0;
-    P = std::fma(P, u, 1308.0);
-    P = std::fma(P, u, 12176.0);
-    P = std::fma(P, u, 40320.0);
+    P = fma_c(P, u, 1308.0);
+    P = fma_c(P, u, 12176.0);
+    P = fma_c(P, u, 40320.0);
     P *= u;
     double Q = std::fma(5.0, u, 240.0);
-    Q = std::fma(Q, u, 3924.0);
-    Q = std::fma(Q, u, 24352.0);
-    Q = std::fma(Q, u, 40320.0);
+    Q = fma_c(Q, u, 3924.0);
+    Q = fma_c(Q, u, 24352.0);
+    Q = fma_c(Q, u, 40320.0);
     const double num = std::fma(2.0, xs, 9.0) * Q;
     const double xp = big ? x : x + 10.0;
     const double rD = fast_rcp(big ? x : xp * P);
@@ -130,12 +145,12 @@ SCHPF_SF double digamma_less_log(double x, double inv_rate)
     const double S = big ? 0.0 : num * rD * xp;         // num / P
     const double z = r * r;
     double p = 8.33333333333333333333E-2;
-    p = std::fma(p, z, -2.10927960927960927961E-2);
-    p = std::fma(p, z, 7.57575757575757575758E-3);
-    p = std::fma(p, z, -4.16666666666666666667E-3);
-    p = std::fma(p, z, 3.96825396825396825397E-3);
-    p = std::fma(p, z, -8.33333333333333333333E-3);
-    p = std::fma(p, z, 8.33333333333333333333E-2);
+    p = fma_c(p, z, -2.10927960927960927961E-2);
+    p = fma_c(p, z, 7.57575757575757575758E-3);
+    p = fma_c(p, z, -4.16666666666666666667E-3);
+    p = fma_c(p, z, 3.96825396825396825397E-3);
+    p = fma_c(p, z, -8.33333333333333333333E-3);
+    p = fma_c(p, z, 8.33333333333333333333E-2);
     return fast_log(xp * inv_rate) - 0.5 * r - z * p - S;
 }
 
