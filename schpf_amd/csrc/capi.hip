@@ -2175,9 +2175,21 @@ int schpf_profile_clock(schpf_ctx *ctx, double *shader_mhz, int64_t *launches)
     if (!shader_mhz || !launches) return fail("output pointer is NULL");
     CTX_CALL(ctx->profile_clock(shader_mhz, launches));
 }
-int schpf_sweep_bytes(schpf_ctx *ctx, int64_t info[8]) { CTX_CALL(ctx->sweep_bytes(info)); }
-int schpf_plan_info(schpf_ctx *ctx, int64_t info[16]) { CTX_CALL(ctx->plan_info(info)); }
-int schpf_upload_info(schpf_ctx *ctx, int64_t info[4]) { CTX_CALL(ctx->upload_info(info)); }
+int schpf_sweep_bytes(schpf_ctx *ctx, int64_t info[8])
+{
+    if (!info) return fail("output pointer is NULL");
+    CTX_CALL(ctx->sweep_bytes(info));
+}
+int schpf_plan_info(schpf_ctx *ctx, int64_t info[16])
+{
+    if (!info) return fail("output pointer is NULL");
+    CTX_CALL(ctx->plan_info(info));
+}
+int schpf_upload_info(schpf_ctx *ctx, int64_t info[4])
+{
+    if (!info) return fail("output pointer is NULL");
+    CTX_CALL(ctx->upload_info(info));
+}
 
 int schpf_coo_marginals(int64_t nnz, const int32_t *row, const int32_t *col, const void *val, int kind,
                         int ncells, int ngenes, double *row_sums, double *col_sums)
